@@ -1,0 +1,194 @@
+"""Pins the CPU oracle (oracle/pvsim_oracle.py) to golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import pvsim_oracle as orc
+from pvsim import synth
+from conftest import load_golden
+
+# Tolerances (documented in DESIGN.md section "Parity"):
+#  * labels: bit-exact (integer) except where the exact fp64 best/second gap is below fp32 noise
+#  * VLAD values fp32: reference sums sequentially in fp32; oracle does the same -> <= 2e-7 abs
+#    (residual difference is np.linalg.norm's summation order)
+#  * Fisher fp64: <= 1e-12 abs   * cosine fp32: <= 3e-7 abs, fp64: <= 1e-14
+VLAD_ATOL = 2e-7
+FISHER_ATOL = 1e-12
+
+
+def _images(g, key_raw="raw_u8", key_off="offsets"):
+    return orc.split_ragged(g[key_raw].astype(np.float32), g[key_off])
+
+
+def test_vlad_k256_labels_and_values(tables):
+    g = load_golden("vlad_k256_d128")
+    C = tables["centroids"]
+    imgs = [synth.rootsift(r) for r in _images(g)]
+    labels = np.concatenate([orc.kmeans_predict(x, C) for x in imgs])
+    assert np.array_equal(labels, g["labels"])            # bit-exact index parity
+    V = orc.vlad_encode(imgs, C)
+    assert V.dtype == np.float32 and V.shape == g["vlad"].shape == (8, 256 * 128)
+    np.testing.assert_allclose(V, g["vlad"], rtol=0, atol=VLAD_ATOL)
+
+
+def test_vlad_structure_known_answers(tables):
+    # notebook shape known-answers: K*D and K+2KD layouts
+    g = load_golden("vlad_k256_d128")
+    assert g["vlad"].shape[1] == 256 * 128
+    assert load_golden("fisher_k256_d128")["fisher"].shape[1] == 256 + 2 * 256 * 128
+    # per-cluster rows are unit L2 or all-zero (intra-normalisation, no global L2)
+    rows = g["vlad"].reshape(8, 256, 128)
+    nrm = np.linalg.norm(rows, axis=2)
+    assert np.all((np.abs(nrm - 1) < 1e-5) | (nrm == 0))
+
+
+def test_vlad_with_pca(tables):
+    g = load_golden("vlad_k256_d128")
+    gp = load_golden("vlad_pca64_k256")
+    imgs = [synth.rootsift(r) for r in _images(g)][: int(gp["n_images"])]
+    V = orc.vlad_encode(imgs, tables["centroids_pca64"], pca=(tables["pca_components"], tables["pca_mean"]))
+    # PCA GEMM summation order differs from sklearn's -> a near-tie label may flip; none does here
+    np.testing.assert_allclose(V, gp["vlad"], rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("default", {}), ("p05", {"power": 0.5}), ("l1", {"norm_order": 1}),
+    ("p03_l1", {"power": 0.3, "norm_order": 1}), ("eps", {"eps": 1e-3})])
+def test_vlad_small_variants(tag, kw):
+    g = load_golden("small_k16_d8")
+    imgs = [r / np.float32(16.0) for r in orc.split_ragged(g["raw"], g["offsets"])]
+    labels = np.concatenate([orc.kmeans_predict(x, g["centroids"]) for x in imgs])
+    assert np.array_equal(labels, g["labels"])
+    assert not np.any(labels == 5)      # centroid 5 duplicates centroid 3: first index wins
+    V = orc.vlad_encode(imgs, g["centroids"], **kw)
+    np.testing.assert_allclose(V, g["vlad_" + tag], rtol=0, atol=VLAD_ATOL)
+
+
+def test_vlad_empty_image_quirk_is_fenced():
+    g = load_golden("small_k16_d8")
+    # reference: a batch with an empty image returns ONE 1-D zero vector (vlad.py:92-93)
+    assert g["empty_quirk"].shape == (16 * 8,) and not g["empty_quirk"].any()
+    # the engine (and oracle) define a zero ROW for that image instead
+    assert not orc.vlad_encode_one(np.zeros((0, 8), np.float32), g["centroids"]).any()
+
+
+def test_gmm_posterior(tables):
+    g = load_golden("vlad_k256_d128")
+    f = load_golden("fisher_k256_d128")
+    x = synth.rootsift(_images(g)[3])
+    r = orc.gmm_predict_proba(x, tables["gmm_weights"], tables["gmm_means"], tables["gmm_covariances"])
+    assert r.dtype == np.float64
+    np.testing.assert_allclose(r, f["resp_img3"], rtol=0, atol=1e-12)
+
+
+def test_fisher_k256(tables):
+    g = load_golden("vlad_k256_d128")
+    f = load_golden("fisher_k256_d128")
+    imgs = [synth.rootsift(r) for r in _images(g)]
+    F = orc.fisher_encode([imgs[i] for i in f["image_index"]],
+                          tables["gmm_weights"], tables["gmm_means"], tables["gmm_covariances"])
+    assert F.dtype == np.float64
+    np.testing.assert_allclose(F, f["fisher"], rtol=0, atol=FISHER_ATOL)
+    np.testing.assert_allclose(np.linalg.norm(F, axis=1), 1.0, atol=1e-8)   # global L2
+
+
+def test_fisher_with_pca(tables):
+    g = load_golden("vlad_k256_d128")
+    f = load_golden("fisher_pca64_k64")
+    imgs = [synth.rootsift(r) for r in _images(g)][: int(f["n_images"])]
+    F = orc.fisher_encode(imgs, tables["gmmp_weights"], tables["gmmp_means"], tables["gmmp_covariances"],
+                          pca=(tables["pca_components"], tables["pca_mean"]))
+    # the fp32 PCA GEMM's summation order differs from sklearn's BLAS call (~1e-7 on the projected
+    # descriptors); the sqrt power-norm amplifies that on near-zero elements -> 2e-6 abs
+    np.testing.assert_allclose(F, f["fisher"], rtol=0, atol=2e-6)
+
+
+def test_fisher_deep_like():
+    f = load_golden("fisher_deep_k32_d96")
+    F = orc.fisher_encode(list(f["desc"]), f["gmm_weights"], f["gmm_means"], f["gmm_covariances"])
+    np.testing.assert_allclose(F, f["fisher"], rtol=0, atol=FISHER_ATOL)
+
+
+@pytest.mark.parametrize("tag,kw", [("default", {}), ("p1", {"power": 1.0}),
+                                    ("l1", {"norm_order": 1}), ("p03", {"power": 0.3})])
+def test_fisher_small_variants(tag, kw):
+    g = load_golden("small_k16_d8")
+    imgs = [r / np.float32(16.0) for r in orc.split_ragged(g["raw"], g["offsets"])]
+    F = orc.fisher_encode(imgs, g["gmm_weights"], g["gmm_means"], g["gmm_covariances"], **kw)
+    np.testing.assert_allclose(F, g["fisher_" + tag], rtol=0, atol=FISHER_ATOL)
+
+
+def test_cosine():
+    g = load_golden("cosine")
+    c32 = orc.cosine_similarity(g["a32"], g["b32"])
+    assert c32.dtype == np.float32
+    np.testing.assert_allclose(c32, g["cos32"], rtol=0, atol=3e-7)
+    assert not c32[:, 2].any()                                   # zero row stays zero
+    assert np.array_equal(c32[:, 7], c32[:, 4])                  # duplicate rows tie exactly
+    c64 = orc.cosine_similarity(g["a32"].astype(np.float64) * 1.7, g["b32"].astype(np.float64))
+    assert c64.dtype == np.float64
+    np.testing.assert_allclose(c64, g["cos64"], rtol=0, atol=1e-14)
+    cm = orc.cosine_similarity(g["a32"], g["b32"].astype(np.float64))
+    assert cm.dtype == np.float64
+    np.testing.assert_allclose(cm, g["cos_mixed"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(orc.cosine_similarity(g["a32"][0], g["b32"][1]), g["cos_1d"], atol=3e-7)
+    with pytest.raises(ValueError):
+        orc.cosine_similarity(np.ones((2, 1), np.float32), np.ones((2, 1), np.float32))
+
+
+def test_cosine_on_vlad_and_similarity_score(tables):
+    g = load_golden("vlad_k256_d128")
+    c = load_golden("cosine")
+    np.testing.assert_allclose(orc.cosine_similarity(g["vlad"], g["vlad"]), c["vlad_self"], atol=5e-7)
+    imgs = [synth.rootsift(r) for r in _images(g)]
+    V = orc.vlad_encode(imgs, tables["centroids"])
+    s = np.float32(orc.cosine_similarity(V[:3], V[2:7]))          # _base_encoder.py:371-385
+    np.testing.assert_allclose(s, c["similarity_score_3x5"], atol=5e-7)
+
+
+def test_pipeline_hstack(tables):
+    g = load_golden("vlad_k256_d128")
+    p = load_golden("pipeline")
+    imgs = [synth.rootsift(r) for r in _images(g)][1:4]
+    V = orc.vlad_encode(imgs, tables["centroids"])
+    F = orc.fisher_encode(imgs, tables["gmm_weights"], tables["gmm_means"], tables["gmm_covariances"])
+    P = np.hstack([V, F])                                           # pipeline.py:47-66
+    assert P.shape == p["encoded"].shape
+    np.testing.assert_allclose(P, p["encoded"], atol=VLAD_ATOL)
+    np.testing.assert_allclose(np.float32(orc.cosine_similarity(P[:2], P[1:3])), p["score"], atol=5e-7)
+
+
+def test_retrieval_and_eval(tables):
+    g = load_golden("eval_db64")
+    C = tables["centroids"]
+    db = [synth.rootsift(r) for r in _images(g, "db_raw_u8", "db_offsets")]
+    qs = [synth.rootsift(r) for r in _images(g, "q_raw_u8", "q_offsets")]
+    dbv, qv = orc.vlad_encode(db, C), orc.vlad_encode(qs, C)
+    sims = orc.cosine_similarity(qv, dbv)
+    np.testing.assert_allclose(sims, g["sims"], atol=5e-7)
+    # the golden is tie-free where it matters: inside the top-8 window consecutive sorted scores
+    # are further apart than fp32 GEMM-order noise
+    srt = -np.sort(-g["sims"], axis=1)
+    gaps = srt[:, :-1] - srt[:, 1:]
+    assert np.min(gaps[:, :8]) > 2e-6
+    idx, val = orc.topk(sims, 7)
+    assert np.array_equal(idx, g["top7_index"])                   # bit-identical top-k lists
+    np.testing.assert_allclose(val, g["top7_score"], atol=5e-7)
+    clear = gaps.min(axis=1) > 2e-6                               # rows whose full ranking is tie-free
+    assert clear.sum() >= 6
+    assert np.array_equal(np.argsort(-sims, axis=1, kind="stable")[clear], g["full_argsort"][clear])
+    for k, key in ((1, "acc_k1"), (5, "acc_k5")):
+        assert orc.top_k_accuracy(qv, g["q_labels"], dbv, g["db_labels"], k) == float(g[key])
+    for k, key in ((None, "map_all"), (5, "map_k5"), (10, "map_k10")):
+        assert abs(orc.top_k_map(qv, g["q_labels"], dbv, g["db_labels"], k) - float(g[key])) < 1e-12
+
+
+def test_near_tie_labels_are_only_near_ties(tables):
+    """Where fp32 labels differ from exact fp64 labels the fp64 margin must be below fp32 noise."""
+    rng = np.random.default_rng(77)
+    x = synth.rootsift(synth.sift_like(50000, rng))
+    C = tables["centroids"]
+    lab32 = orc.kmeans_predict(x, C)
+    lab64, gap = orc.assignment_margin(x, C)
+    bad = lab32 != lab64
+    assert bad.sum() <= 5 and np.all(gap[bad] < 2e-6)
