@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec encoded + top-k retrieved, VLAD K=256 RootSIFT (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over the whole synthetic corpus, inputs already resident in HBM:
+  encode  : descriptors -> KMeans assignment -> VLAD residual aggregation -> power + intra L2 norm
+  exchange: (N > 1) RCCL all-gather of the per-GPU encoding blocks
+  retrieve: every image queries the whole corpus: N x N cosine GEMM + top-k (k = 5)
+Workload at 1 GPU = BASELINE.json configs[1]: 8189 images (Oxford-102 sized), ragged descriptor counts
+(LogNormal around 1257), D = 128, K = 256.  With N GPUs the same corpus is sharded by image
+(strong scaling); each rank scores its own query block against the gathered corpus.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "python-visual-similarity_amd"))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+K_CLUSTERS, DIM, TOPK = 256, 128, 5
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--images", type=int, default=8189)
+    ap.add_argument("--desc", choices=["f32", "u8"], default="f32",
+                    help="descriptor rows in HBM: fp32 RootSIFT (default) or raw uint8 SIFT with fused RootSIFT")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcie", action="store_true", help="also time one step with host-resident inputs (H2D included)")
+    return ap.parse_args()
+
+
+def make_corpus(n_images, seed, device):
+    """Synthetic SIFT-like descriptors generated ON DEVICE (torch is plumbing here): a prototype histogram
+    times log-normal noise plus a sparse floor, scaled to L2 = 512, clipped to 255, rounded -> uint8."""
+    import torch
+    from pvsim import synth
+    counts = synth.ragged_counts(n_images, seed)
+    offsets = np.zeros(n_images + 1, np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    total = int(offsets[-1])
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    proto = torch.from_numpy(synth.sift_prototypes().astype(np.float32)).to(device)
+    raw = torch.empty((total, DIM), dtype=torch.uint8, device=device)
+    step = 1 << 20
+    for s in range(0, total, step):
+        e = min(total, s + step)
+        z = torch.randint(0, proto.shape[0], (e - s,), generator=g, device=device)
+        x = proto[z] * torch.exp(0.35 * torch.randn((e - s, DIM), generator=g, device=device))
+        x = x + 1.2 * torch.rand((e - s, DIM), generator=g, device=device) ** 3 * 4.0
+        x = x * (512.0 / x.norm(dim=1, keepdim=True).clamp_min(1e-9))
+        raw[s:e] = x.clamp_max(255.0).round().to(torch.uint8)
+    return raw, offsets
+
+
+def rootsift_torch(raw_u8):
+    """fp32 RootSIFT rows, same arithmetic as the reference extractor tail (features/_features.py:112-114)."""
+    import torch
+    out = torch.empty(raw_u8.shape, dtype=torch.float32, device=raw_u8.device)
+    step = 1 << 20
+    for s in range(0, raw_u8.shape[0], step):
+        x = raw_u8[s:s + step].float()
+        out[s:s + step] = torch.sqrt(x / (x.sum(dim=1, keepdim=True) + 1e-7))
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import pvsim
+    from pvsim.engine import DESC_F32, DESC_U8_ROOTSIFT
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    ctx = pvsim.Context(local)
+    tables = np.load(os.path.join(REPO, "tests", "golden", "tables_k256_d128.npz"), allow_pickle=False)
+    cb = ctx.codebook(tables["centroids"])
+
+    # ---- corpus, sharded by image: rank r owns images [lo, hi)
+    N = args.images
+    raw_all_counts_seed = 1235
+    per = (N + world - 1) // world
+    lo, hi = min(N, rank * per), min(N, (rank + 1) * per)
+    n_loc = hi - lo
+    # every rank generates only its own shard (seeded per rank so shards differ)
+    raw, offsets = make_corpus(n_loc, raw_all_counts_seed + 7919 * rank, dev)
+    total_desc = int(offsets[-1])
+    kind = DESC_U8_ROOTSIFT if args.desc == "u8" else DESC_F32
+    desc = raw if args.desc == "u8" else rootsift_torch(raw)
+    d_off = torch.from_numpy(offsets).to(dev)
+    L = K_CLUSTERS * DIM
+    enc_loc = torch.empty((per, L), dtype=torch.float32, device=dev)       # padded to the common block size
+    inv_loc = torch.ones((per,), dtype=torch.float32, device=dev)
+    if n_loc < per:
+        enc_loc[n_loc:].zero_()
+    if world > 1:
+        enc_all = torch.empty((world * per, L), dtype=torch.float32, device=dev)
+        inv_all = torch.empty((world * per,), dtype=torch.float32, device=dev)
+    else:
+        enc_all, inv_all = enc_loc, inv_loc
+    idx = torch.empty((max(n_loc, 1), TOPK), dtype=torch.int64, device=dev)
+    val = torch.empty((max(n_loc, 1), TOPK), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.vlad_encode_dev(cb, desc.data_ptr(), kind, d_off.data_ptr(), n_loc, total_desc, enc_loc.data_ptr(),
+                            d_inv_norm=inv_loc.data_ptr())
+        if world > 1:
+            ctx.sync()                                   # encode (ctx stream) -> collective (torch stream)
+            dist.all_gather_into_tensor(enc_all, enc_loc)
+            dist.all_gather_into_tensor(inv_all, inv_loc)
+            torch.cuda.current_stream().synchronize()
+        for s in range(world):                           # score against every rank's block (true global indices)
+            s_lo, s_hi = min(N, s * per), min(N, (s + 1) * per)
+            if s_hi > s_lo and n_loc > 0:
+                ctx.cosine_topk_dev(enc_loc.data_ptr(), n_loc, enc_all[s * per:].data_ptr(), s_hi - s_lo, L,
+                                    inv_loc.data_ptr(), inv_all[s * per:].data_ptr(), TOPK, s_lo, s > 0,
+                                    idx.data_ptr(), val.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timers_enable(True)
+    ctx.timers_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timers = ctx.timers()
+    ctx.timers_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = N / (dt / args.steps)
+
+    # ---- sanity inside the bench: self-retrieval must return the image itself first
+    got = idx[:n_loc, 0].cpu().numpy()
+    assert np.array_equal(got, np.arange(lo, hi)), "self-retrieval failed: top-1 is not the query image"
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (the cosine GEMM): algorithmic flop / measured launch duration
+    gemm_ms, gemm_n = timers["cosine_gemm"]
+    flop_per_launch = 2.0 * n_loc * (min(per, N)) * L      # one launch = local queries x one rank block
+    gemm_avg_ms = gemm_ms / max(gemm_n, 1)
+    achieved = flop_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
+    stages = {k: {"ms_total": round(v[0], 3), "launches": int(v[1]),
+                  "ms_avg": round(v[0] / v[1], 4) if v[1] else None} for k, v in timers.items() if v[1]}
+    enc_ms = (timers["assign"][0] + timers["aggregate"][0]) / args.steps
+    desc_bytes = total_desc * DIM * (1 if args.desc == "u8" else 4)
+    enc_bytes = desc_bytes + n_loc * L * 4
+    out = {
+        "metric": "images/sec encoded + top-k retrieved, VLAD K256 RootSIFT",
+        "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {N} images x ragged SIFT-like descriptors (mean {total_desc / max(n_loc, 1):.0f}/image),"
+                               f" D=128, VLAD K=256 encode + {N}x{N} cosine + top-{TOPK}",
+                   "images": N, "descriptors_rank0": total_desc, "descriptor_rows": args.desc,
+                   "K": K_CLUSTERS, "D": DIM, "topk": TOPK, "parallelism": f"image-sharded x{world}"},
+        "roofline": {"kernel": "cosine_gemm_f32_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                     "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_ms": round(gemm_avg_ms, 4)},
+        "stages": stages,
+        "encode": {"ms_per_step": round(enc_ms, 3), "images_per_s": round(n_loc / (enc_ms * 1e-3), 1) if enc_ms else None,
+                   "algorithmic_GBps": round(enc_bytes / (enc_ms * 1e-3) / 1e9, 1) if enc_ms else None,
+                   "assign_TFLOPs": round(2.0 * total_desc * K_CLUSTERS * DIM / (timers["assign"][0] / args.steps * 1e-3) / 1e12, 2)
+                   if timers["assign"][0] else None},
+        "device": ctx.device_name(),
+    }
+
+    if args.pcie and world == 1:
+        h_desc = desc.cpu().numpy()
+        t1 = time.perf_counter()
+        v = ctx.vlad_encode(cb, h_desc, offsets, kind)
+        ctx.cosine_topk(v, v, TOPK)
+        out["pcie_inclusive_images_per_s"] = round(N / (time.perf_counter() - t1), 1)
+
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(raw, offsets, tables["centroids"], enc_loc[:n_loc], N)
+
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(raw, offsets, centroids, enc_dev, n_images):
+    """The oracle's C restatement (a 'port' of the reference's per-image / per-query procedure: assign ->
+    sequential residual sums -> normalise; per query cosine against the WHOLE re-normalised database -> full
+    sort -> first k), timed on this host's cores over a bounded sample of the same corpus."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import pvsim_oracle_c as orc_c
+    threads = orc_c.max_threads()
+    n_enc = min(n_images, max(64, 16 * threads))
+    sub_off = offsets[: n_enc + 1].copy()
+    sub_raw = raw[: int(sub_off[-1])].cpu().numpy()
+    orc_c.vlad_encode(sub_raw[: int(sub_off[8])], sub_off[:9], centroids)            # warm the thread pool
+    t0 = time.perf_counter()
+    v = orc_c.vlad_encode(sub_raw, sub_off, centroids)
+    t_enc = (time.perf_counter() - t0) / n_enc
+    db = enc_dev.cpu().numpy()
+    n_q = min(n_images, max(threads, 16))
+    t0 = time.perf_counter()
+    orc_c.retrieve(db[:n_q], db, TOPK)
+    t_ret = (time.perf_counter() - t0) / n_q
+    return {"value": round(1.0 / (t_enc + t_ret), 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n_enc} images encoded + {n_q} queries retrieved against all {n_images} encodings "
+                      f"(OpenMP, {threads} threads); per-image cost = encode {t_enc * 1e3:.2f} ms + retrieve {t_ret * 1e3:.2f} ms",
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/*
+ * pvsim.h -- C-ABI of libpvsim_hip.so: the MI355X (gfx950) hot path of an image-similarity engine
+ * that is a drop-in for pyvisim's VLADEncoder / FisherVectorEncoder / cosine_similarity / eval top-k.
+ *
+ * The reference (MechaCritter/Python-Visual-Similarity, pure Python) has no FFI layer; its extension
+ * points are Python objects.  This header is therefore the NEW boundary that sits
+ * directly beneath those Python methods; each entry point names the reference code it replaces
+ * (paths relative to the reference root).  The Python package `pvsim` binds it with ctypes
+ * (python-visual-similarity_amd/pvsim/_ffi.py); INTEGRATION.md shows the binding a pyvisim maintainer
+ * would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no C++/torch types.
+ *   - every function returns a pvs_status (0 = ok).  pvs_last_error() returns a thread-local message.
+ *     No exception or abort crosses the ABI.
+ *   - the library never owns host memory: outputs are caller-allocated, C-contiguous.
+ *   - device tables live behind opaque handles with explicit create/destroy.
+ *   - one pvs_ctx = one device + one HIP stream.  Entry points ending in `_dev` take DEVICE pointers
+ *     (e.g. torch.Tensor.data_ptr(), or pvs_malloc memory), enqueue on the context's stream and return
+ *     without synchronising; all others take HOST pointers and block until the result is in host memory.
+ *   - there is no CPU fallback: without a GPU every compute entry point fails with PVS_ERR_NO_DEVICE.
+ */
+#ifndef PVSIM_H
+#define PVSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVS_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+  PVS_OK = 0,
+  PVS_ERR_INVALID = 1,     /* bad argument                      -> ValueError   */
+  PVS_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime error -> RuntimeError */
+  PVS_ERR_OOM = 3,         /* device allocation failed          -> MemoryError  */
+  PVS_ERR_UNSUPPORTED = 4, /* shape / option not implemented    -> NotImplementedError */
+  PVS_ERR_DIM = 5          /* dimension mismatch                -> RuntimeError (as the reference raises) */
+} pvs_status;
+
+/* How descriptor rows are stored, and whether the RootSIFT tail
+ * (pyvisim/features/_features.py:112-114: d /= sum(d)+1e-7; d = sqrt(d)) is fused into the load. */
+typedef enum {
+  PVS_DESC_F32 = 0,          /* float32 rows used as they are                                */
+  PVS_DESC_F32_ROOTSIFT = 1, /* float32 raw SIFT rows (0..255), RootSIFT applied on the fly  */
+  PVS_DESC_U8_ROOTSIFT = 2   /* uint8  raw SIFT rows, RootSIFT applied on the fly (4x fewer HBM bytes) */
+} pvs_desc_kind;
+
+typedef struct pvs_ctx pvs_ctx;
+typedef struct pvs_codebook pvs_codebook; /* KMeans.cluster_centers_ (K,D) f32 + ||c||^2                */
+typedef struct pvs_gmm pvs_gmm;           /* GaussianMixture weights_/means_/covariances_ ('diag')     */
+typedef struct pvs_pca pvs_pca;           /* PCA components_ (C,Din) + mean_                            */
+
+/* Normalisation knobs shared by both encoders -- the constructor kwargs of
+ * VLADEncoder (pyvisim/encoders/vlad.py:42-53) and FisherVectorEncoder (fisher_vector.py:41-51). */
+typedef struct {
+  double power_norm_weight; /* p in sign(v)|v|^p ; VLAD default 1, Fisher default 0.5 */
+  double norm_order;        /* ord of np.linalg.norm: 1, 2, any p > 0, or +INFINITY   */
+  double epsilon;           /* added to the norm before dividing (default 1e-9)       */
+} pvs_norm_params;
+
+/* ---------------------------------------------------------------- context / errors */
+int pvs_version(void);
+const char* pvs_last_error(void);
+int pvs_device_count(int* count);
+/* stream == NULL: the context creates and owns a stream.  Otherwise `stream` is a hipStream_t the
+ * caller owns (e.g. torch.cuda.current_stream().cuda_stream) and all work is enqueued there. */
+int pvs_init(int device_id, void* stream, pvs_ctx** out);
+int pvs_destroy(pvs_ctx* ctx);
+int pvs_sync(pvs_ctx* ctx);
+void* pvs_stream(pvs_ctx* ctx);
+int pvs_device_name(pvs_ctx* ctx, char* buf, size_t buflen);
+
+/* plain device memory for hosts that do not use torch */
+int pvs_malloc(pvs_ctx* ctx, size_t bytes, void** dptr);
+int pvs_free(pvs_ctx* ctx, void* dptr);
+int pvs_memcpy_h2d(pvs_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int pvs_memcpy_d2h(pvs_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int pvs_memset(pvs_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* ---------------------------------------------------------------- tables (host pointers in) */
+/* replaces reading KMeans.cluster_centers_ per image (vlad.py:96) */
+int pvs_codebook_create(pvs_ctx* ctx, const float* centroids /*[K*D]*/, int K, int D, pvs_codebook** out);
+int pvs_codebook_destroy(pvs_ctx* ctx, pvs_codebook* cb);
+/* replaces reading weights_/means_/covariances_ per image (fisher_vector.py:95-97); fp64 in, as sklearn stores */
+int pvs_gmm_create(pvs_ctx* ctx, const double* weights /*[K]*/, const double* means /*[K*D]*/,
+                   const double* covariances /*[K*D]*/, int K, int D, pvs_gmm** out);
+int pvs_gmm_destroy(pvs_ctx* ctx, pvs_gmm* g);
+/* replaces PCA.transform (vlad.py:89-90, fisher_vector.py:91-92) */
+int pvs_pca_create(pvs_ctx* ctx, const float* components /*[C*Din]*/, const float* mean /*[Din]*/,
+                   int n_components, int d_in, pvs_pca** out);
+int pvs_pca_destroy(pvs_ctx* ctx, pvs_pca* p);
+
+/* ---------------------------------------------------------------- VLAD: vlad.py:81-115
+ * desc: packed rows of all images [offsets[n_images]][D_in]; offsets: int64[n_images+1] (CSR style).
+ * pca may be NULL.  out: float32 [n_images][K*D] (k-major, flatten=True layout).  An image with zero
+ * descriptors yields a zero row (the reference aborts the batch, vlad.py:92-93 -- fenced quirk).
+ * out_labels (optional): int32 [total descriptors], the KMeans.predict labels (vlad.py:95).
+ * out_inv_norm (optional, _dev only): float32 [n_images], 1/||row||_2 (1 for zero rows) for the cosine step. */
+int pvs_vlad_encode(pvs_ctx* ctx, const pvs_codebook* cb, const pvs_pca* pca, const void* desc,
+                    int desc_kind, const int64_t* offsets, int64_t n_images, const pvs_norm_params* prm,
+                    float* out, int32_t* out_labels);
+int pvs_vlad_encode_dev(pvs_ctx* ctx, const pvs_codebook* cb, const pvs_pca* pca, const void* d_desc,
+                        int desc_kind, const int64_t* d_offsets, int64_t n_images, int64_t total_desc,
+                        const pvs_norm_params* prm, float* d_out, int32_t* d_labels, float* d_inv_norm);
+/* KMeans.predict alone (vlad.py:95 -> sklearn _k_means_lloyd.pyx:168-218) */
+int pvs_kmeans_predict_dev(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int desc_kind,
+                           int64_t total_desc, int32_t* d_labels);
+
+/* ---------------------------------------------------------------- Fisher: fisher_vector.py:83-135
+ * out: [n_images][K + 2*K*D]  laid out [d_pi | d_mu (k-major) | d_sigma].  The host form returns
+ * float64 (the reference's dtype); the device form writes float32 or float64 (out_f64 != 0). */
+int pvs_fisher_encode(pvs_ctx* ctx, const pvs_gmm* g, const pvs_pca* pca, const void* desc, int desc_kind,
+                      const int64_t* offsets, int64_t n_images, const pvs_norm_params* prm, double* out);
+int pvs_fisher_encode_dev(pvs_ctx* ctx, const pvs_gmm* g, const pvs_pca* pca, const void* d_desc,
+                          int desc_kind, const int64_t* d_offsets, int64_t n_images, int64_t total_desc,
+                          const pvs_norm_params* prm, void* d_out, int out_f64);
+/* GaussianMixture.predict_proba alone (fisher_vector.py:99), float64 [total][K] */
+int pvs_gmm_predict_proba_dev(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int desc_kind,
+                              int64_t total_desc, double* d_resp);
+/* PCA.transform alone: float32 [total][C] */
+int pvs_pca_transform_dev(pvs_ctx* ctx, const pvs_pca* p, const void* d_desc, int desc_kind,
+                          int64_t total_desc, float* d_out);
+
+/* ---------------------------------------------------------------- cosine: pyvisim/_utils.py:312-330
+ * (-> sklearn.metrics.pairwise.cosine_similarity): rows L2-normalised (zero rows stay zero), A.B^T.
+ * is_f64 != 0: operands and output are float64 (the reference's dtype rule: fp32 iff both fp32). */
+int pvs_cosine(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, int is_f64,
+               void* out /*[M*N]*/);
+int pvs_row_inv_norms_dev(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L, float* d_inv);
+/* out[i*ldo + j] = (A_i . B_j) * inv_a[i] * inv_b[j]; inv_* may be NULL (treated as 1). */
+int pvs_cosine_dev(pvs_ctx* ctx, const float* d_A, int64_t M, const float* d_B, int64_t N, int64_t L,
+                   const float* d_inv_a, const float* d_inv_b, float* d_out, int64_t ldo);
+
+/* ---------------------------------------------------------------- top-k: pyvisim/eval.py:37-43,75-80,131-132
+ * per query row: np.argsort(-scores)[:k].  Order is (score desc, index asc); NaN scores rank last.
+ * pvs_topk_dev consumes a score panel [nq][ncols] (row stride ld) whose column 0 has global index
+ * col_offset; with merge != 0 the panel is merged into the running lists already in d_idx/d_val.
+ * d_idx: int64 [nq*k], d_val: float32 [nq*k]. */
+int pvs_topk_dev(pvs_ctx* ctx, const float* d_scores, int64_t nq, int64_t ncols, int64_t ld, int k,
+                 int64_t col_offset, int merge, int64_t* d_idx, float* d_val);
+/* cosine + top-k without materialising the full nq x N matrix (tiled through a workspace panel). */
+int pvs_cosine_topk_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L,
+                        const float* d_inv_q, const float* d_inv_db, int k, int64_t col_offset, int merge,
+                        int64_t* d_idx, float* d_val);
+int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L, int k,
+                    int64_t* out_idx, float* out_val);
+/* merges per-rank top-k lists (multi-GPU: each rank scored its own DB shard): lists [n_lists][nq][k]. */
+int pvs_topk_merge_dev(pvs_ctx* ctx, const int64_t* d_idx_lists, const float* d_val_lists, int n_lists,
+                       int64_t nq, int k, int64_t* d_idx, float* d_val);
+
+/* ---------------------------------------------------------------- measurement hooks (bench.py) */
+/* Enable per-kernel-family HIP-event timing on the context's stream. which: 0 assign, 1 aggregate,
+ * 2 cosine gemm, 3 top-k, 4 fisher posterior, 5 fisher moments, 6 norms/misc. */
+#define PVS_TIMER_SLOTS 8
+int pvs_timers_enable(pvs_ctx* ctx, int on);
+int pvs_timers_reset(pvs_ctx* ctx);
+int pvs_timers_read(pvs_ctx* ctx, int which, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVSIM_H */

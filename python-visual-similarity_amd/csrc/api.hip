@@ -1,0 +1,675 @@
+// C-ABI of libpvsim_hip.so (declared in include/pvsim.h): context, tables, and the host-pointer /
+// device-pointer entry points that sequence the kernels of vlad.hip, fisher.hip, cosine.hip, topk.hip.
+#include <algorithm>
+#include <limits>
+
+#include "common.hpp"
+
+namespace pvs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int ws_reserve(pvs_ctx* ctx, int which, size_t bytes, void** out) {
+  if (bytes == 0) bytes = 16;
+  if (ctx->ws_bytes[which] < bytes) {
+    if (ctx->ws[which]) {
+      PVS_HIP(hipStreamSynchronize(ctx->stream));  // earlier work may still read the old block
+      PVS_HIP(hipFree(ctx->ws[which]));
+      ctx->ws[which] = nullptr;
+      ctx->ws_bytes[which] = 0;
+    }
+    const size_t want = bytes + bytes / 8;
+    PVS_HIP(hipMalloc(&ctx->ws[which], want));
+    ctx->ws_bytes[which] = want;
+  }
+  *out = ctx->ws[which];
+  return PVS_OK;
+}
+
+static int drain_timers(pvs_ctx* ctx) {
+  if (ctx->pending.empty()) return PVS_OK;
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      ctx->t_total[r.slot] += ms;
+      ctx->t_count[r.slot] += 1;
+    }
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  ctx->pending.clear();
+  return PVS_OK;
+}
+
+template <typename T>
+static int upload(pvs_ctx* ctx, T** dptr, const T* host, size_t count) {
+  PVS_HIP(hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(count, 1) * sizeof(T)));
+  PVS_HIP(hipMemcpyAsync(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return PVS_OK;
+}
+
+static size_t desc_elem_size(int kind) { return kind == PVS_DESC_U8_ROOTSIFT ? 1 : 4; }
+
+static int check_kind(int kind) {
+  if (kind != PVS_DESC_F32 && kind != PVS_DESC_F32_ROOTSIFT && kind != PVS_DESC_U8_ROOTSIFT)
+    PVS_FAIL(PVS_ERR_INVALID, "unknown descriptor kind %d", kind);
+  return PVS_OK;
+}
+
+int assign_tiles_for(int K);  // vlad.hip
+
+}  // namespace pvs
+
+using namespace pvs;
+
+#define PVS_NEED(p, what) \
+  if (!(p)) PVS_FAIL(PVS_ERR_INVALID, "%s: null %s", __func__, what)
+
+// ================================================================================ context
+PVS_EXPORT int pvs_version(void) { return PVS_VERSION; }
+PVS_EXPORT const char* pvs_last_error(void) { return g_err; }
+
+PVS_EXPORT int pvs_device_count(int* count) {
+  PVS_NEED(count, "count");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *count = n;
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_init(int device_id, void* stream, pvs_ctx** out) {
+  PVS_NEED(out, "out");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    PVS_FAIL(PVS_ERR_NO_DEVICE, "no HIP device visible: this engine has no CPU fallback");
+  if (device_id < 0 || device_id >= n) PVS_FAIL(PVS_ERR_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
+  PVS_HIP(hipSetDevice(device_id));
+  pvs_ctx* c = new pvs_ctx();
+  c->device = device_id;
+  if (stream) {
+    c->stream = static_cast<hipStream_t>(stream);
+  } else {
+    PVS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->owns_stream = true;
+  }
+  hipDeviceProp_t prop;
+  PVS_HIP(hipGetDeviceProperties(&prop, device_id));
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    delete c;
+    PVS_FAIL(PVS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id,
+             prop.gcnArchName);
+  }
+  *out = c;
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_destroy(pvs_ctx* ctx) {
+  if (!ctx) return PVS_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  drain_timers(ctx);
+  for (int i = 0; i < pvs_ctx::NWS; ++i)
+    if (ctx->ws[i]) hipFree(ctx->ws[i]);
+  if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_sync(pvs_ctx* ctx) {
+  PVS_NEED(ctx, "ctx");
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  return PVS_OK;
+}
+
+PVS_EXPORT void* pvs_stream(pvs_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+PVS_EXPORT int pvs_device_name(pvs_ctx* ctx, char* buf, size_t buflen) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(buf, "buf");
+  hipDeviceProp_t prop;
+  PVS_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_malloc(pvs_ctx* ctx, size_t bytes, void** dptr) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(dptr, "dptr");
+  PVS_HIP(hipSetDevice(ctx->device));
+  PVS_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+  return PVS_OK;
+}
+PVS_EXPORT int pvs_free(pvs_ctx* ctx, void* dptr) {
+  PVS_NEED(ctx, "ctx");
+  if (dptr) {
+    PVS_HIP(hipStreamSynchronize(ctx->stream));
+    PVS_HIP(hipFree(dptr));
+  }
+  return PVS_OK;
+}
+PVS_EXPORT int pvs_memcpy_h2d(pvs_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  PVS_NEED(ctx, "ctx");
+  PVS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  return PVS_OK;
+}
+PVS_EXPORT int pvs_memcpy_d2h(pvs_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  PVS_NEED(ctx, "ctx");
+  PVS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  return PVS_OK;
+}
+PVS_EXPORT int pvs_memset(pvs_ctx* ctx, void* dst, int value, size_t bytes) {
+  PVS_NEED(ctx, "ctx");
+  PVS_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+  return PVS_OK;
+}
+
+// ================================================================================ tables
+PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, int D, pvs_codebook** out) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(centroids, "centroids");
+  PVS_NEED(out, "out");
+  if (K < 1 || D < 1) PVS_FAIL(PVS_ERR_INVALID, "codebook: K and D must be positive (K=%d, D=%d)", K, D);
+  PVS_HIP(hipSetDevice(ctx->device));
+  pvs_codebook* cb = new pvs_codebook();
+  cb->K = K;
+  cb->D = D;
+  const int nt = assign_tiles_for(K);
+  cb->K_pad = (K + 32 * nt - 1) / (32 * nt) * (32 * nt);
+  cb->D_pad = (D + 7) / 8 * 8;
+  std::vector<float> pad((size_t)cb->K_pad * cb->D_pad, 0.f), cn(cb->K_pad, std::numeric_limits<float>::infinity());
+  for (int k = 0; k < K; ++k) {
+    // ||c||^2 in fp32 (sklearn row_norms(squared=True) on the fp32 centres)
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float v = centroids[(size_t)k * D + d];
+      pad[(size_t)k * cb->D_pad + d] = v;
+      s += v * v;
+    }
+    cn[k] = s;
+  }
+  int st = upload(ctx, &cb->d_cent, centroids, (size_t)K * D);
+  if (st == PVS_OK) st = upload(ctx, &cb->d_cpad, pad.data(), pad.size());
+  if (st == PVS_OK) st = upload(ctx, &cb->d_cnorm, cn.data(), cn.size());
+  if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
+  if (st != PVS_OK) {
+    pvs_codebook_destroy(ctx, cb);
+    return st;
+  }
+  *out = cb;
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_codebook_destroy(pvs_ctx* ctx, pvs_codebook* cb) {
+  if (!cb) return PVS_OK;
+  if (ctx) hipStreamSynchronize(ctx->stream);
+  if (cb->d_cent) hipFree(cb->d_cent);
+  if (cb->d_cpad) hipFree(cb->d_cpad);
+  if (cb->d_cnorm) hipFree(cb->d_cnorm);
+  delete cb;
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_gmm_create(pvs_ctx* ctx, const double* weights, const double* means, const double* covariances,
+                              int K, int D, pvs_gmm** out) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(weights, "weights");
+  PVS_NEED(means, "means");
+  PVS_NEED(covariances, "covariances");
+  PVS_NEED(out, "out");
+  if (K < 1 || D < 1) PVS_FAIL(PVS_ERR_INVALID, "gmm: K and D must be positive (K=%d, D=%d)", K, D);
+  PVS_HIP(hipSetDevice(ctx->device));
+  pvs_gmm* g = new pvs_gmm();
+  g->K = K;
+  g->D = D;
+  // derived tables, fp64, following sklearn/mixture/_gaussian_mixture.py:413-450,495-512 ('diag'):
+  //   prec_chol = 1/sqrt(cov); precisions = prec_chol^2; log_det = sum log(prec_chol)
+  //   const_k = -0.5*(D*log(2 pi) + sum_d mu^2 prec) + log_det + log(w_k)
+  std::vector<double> prec((size_t)K * D), mup((size_t)K * D), cst(K);
+  const double log2pi = std::log(2.0 * M_PI);
+  for (int k = 0; k < K; ++k) {
+    double s = 0.0, ld = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const size_t i = (size_t)k * D + d;
+      const double pc = 1.0 / std::sqrt(covariances[i]);
+      const double p = pc * pc;
+      prec[i] = p;
+      mup[i] = means[i] * p;
+      s += means[i] * means[i] * p;
+      ld += std::log(pc);
+    }
+    cst[k] = -0.5 * (D * log2pi + s) + ld + std::log(weights[k]);
+  }
+  int st = upload(ctx, &g->d_w, weights, (size_t)K);
+  if (st == PVS_OK) st = upload(ctx, &g->d_mu, means, (size_t)K * D);
+  if (st == PVS_OK) st = upload(ctx, &g->d_cov, covariances, (size_t)K * D);
+  if (st == PVS_OK) st = upload(ctx, &g->d_prec, prec.data(), prec.size());
+  if (st == PVS_OK) st = upload(ctx, &g->d_mup, mup.data(), mup.size());
+  if (st == PVS_OK) st = upload(ctx, &g->d_const, cst.data(), cst.size());
+  if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
+  if (st != PVS_OK) {
+    pvs_gmm_destroy(ctx, g);
+    return st;
+  }
+  *out = g;
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_gmm_destroy(pvs_ctx* ctx, pvs_gmm* g) {
+  if (!g) return PVS_OK;
+  if (ctx) hipStreamSynchronize(ctx->stream);
+  for (double* p : {g->d_w, g->d_mu, g->d_cov, g->d_prec, g->d_mup, g->d_const})
+    if (p) hipFree(p);
+  delete g;
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_pca_create(pvs_ctx* ctx, const float* components, const float* mean, int n_components, int d_in,
+                              pvs_pca** out) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(components, "components");
+  PVS_NEED(mean, "mean");
+  PVS_NEED(out, "out");
+  if (n_components < 1 || d_in < 1) PVS_FAIL(PVS_ERR_INVALID, "pca: bad shape (%d, %d)", n_components, d_in);
+  PVS_HIP(hipSetDevice(ctx->device));
+  pvs_pca* p = new pvs_pca();
+  p->C = n_components;
+  p->Din = d_in;
+  // offset = mean @ components^T, fp32 (sklearn/decomposition/_base.py:116-166)
+  std::vector<float> off(n_components);
+  for (int c = 0; c < n_components; ++c) {
+    float s = 0.f;
+    for (int d = 0; d < d_in; ++d) s += mean[d] * components[(size_t)c * d_in + d];
+    off[c] = s;
+  }
+  int st = upload(ctx, &p->d_comp, components, (size_t)n_components * d_in);
+  if (st == PVS_OK) st = upload(ctx, &p->d_off, off.data(), off.size());
+  if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
+  if (st != PVS_OK) {
+    pvs_pca_destroy(ctx, p);
+    return st;
+  }
+  *out = p;
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_pca_destroy(pvs_ctx* ctx, pvs_pca* p) {
+  if (!p) return PVS_OK;
+  if (ctx) hipStreamSynchronize(ctx->stream);
+  if (p->d_comp) hipFree(p->d_comp);
+  if (p->d_off) hipFree(p->d_off);
+  delete p;
+  return PVS_OK;
+}
+
+// ================================================================================ VLAD
+static int check_norm(const pvs_norm_params* prm) {
+  if (!prm) PVS_FAIL(PVS_ERR_INVALID, "null norm params");
+  if (std::isnan(prm->norm_order) || prm->norm_order <= 0.0)
+    PVS_FAIL(PVS_ERR_UNSUPPORTED, "norm_order must be > 0 or +inf (got %g)", prm->norm_order);
+  return PVS_OK;
+}
+
+// optional PCA prologue: returns the descriptor view the encoder kernels should read
+static int project_if_needed(pvs_ctx* ctx, const pvs_pca* pca, int model_dim, const void*& d_desc, int& kind,
+                             int64_t total, int& ld) {
+  if (!pca) {
+    ld = model_dim;
+    return PVS_OK;
+  }
+  if (pca->C != model_dim)
+    PVS_FAIL(PVS_ERR_DIM, "PCA outputs %d components but the clustering model expects %d", pca->C, model_dim);
+  float* proj = nullptr;
+  PVS_TRY(ws_reserve(ctx, 3, (size_t)std::max<int64_t>(total, 1) * pca->C * sizeof(float),
+                     reinterpret_cast<void**>(&proj)));
+  PVS_TRY(launch_pca(ctx, pca, d_desc, kind, total, proj));
+  d_desc = proj;
+  kind = PVS_DESC_F32;
+  ld = pca->C;
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_kmeans_predict_dev(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int desc_kind,
+                                      int64_t total_desc, int32_t* d_labels) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(cb, "codebook");
+  PVS_TRY(check_kind(desc_kind));
+  if (total_desc < 0) PVS_FAIL(PVS_ERR_INVALID, "negative descriptor count");
+  if (total_desc == 0) return PVS_OK;
+  PVS_NEED(d_desc, "descriptors");
+  PVS_NEED(d_labels, "labels");
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_assign(ctx, cb, d_desc, desc_kind, total_desc, cb->D, d_labels);
+}
+
+PVS_EXPORT int pvs_vlad_encode_dev(pvs_ctx* ctx, const pvs_codebook* cb, const pvs_pca* pca, const void* d_desc,
+                                   int desc_kind, const int64_t* d_offsets, int64_t n_images, int64_t total_desc,
+                                   const pvs_norm_params* prm, float* d_out, int32_t* d_labels, float* d_inv_norm) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(cb, "codebook");
+  PVS_TRY(check_kind(desc_kind));
+  PVS_TRY(check_norm(prm));
+  if (n_images < 0 || total_desc < 0) PVS_FAIL(PVS_ERR_INVALID, "negative sizes");
+  if (n_images == 0) return PVS_OK;
+  PVS_NEED(d_offsets, "offsets");
+  PVS_NEED(d_out, "out");
+  if (total_desc > 0) PVS_NEED(d_desc, "descriptors");
+  PVS_HIP(hipSetDevice(ctx->device));
+  int kind = desc_kind, ld = 0;
+  const void* x = d_desc;
+  PVS_TRY(project_if_needed(ctx, pca, cb->D, x, kind, total_desc, ld));
+  int32_t* labels = d_labels;
+  if (!labels)
+    PVS_TRY(ws_reserve(ctx, 1, (size_t)std::max<int64_t>(total_desc, 1) * sizeof(int32_t),
+                       reinterpret_cast<void**>(&labels)));
+  PVS_TRY(launch_assign(ctx, cb, x, kind, total_desc, ld, labels));
+  return launch_vlad_aggregate(ctx, cb, x, kind, ld, d_offsets, n_images, labels, *prm, d_out, d_inv_norm);
+}
+
+static int host_total(const int64_t* offsets, int64_t n_images, int64_t* total) {
+  if (offsets[0] != 0) PVS_FAIL(PVS_ERR_INVALID, "offsets[0] must be 0");
+  for (int64_t i = 0; i < n_images; ++i)
+    if (offsets[i + 1] < offsets[i]) PVS_FAIL(PVS_ERR_INVALID, "offsets must be non-decreasing");
+  *total = offsets[n_images];
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_vlad_encode(pvs_ctx* ctx, const pvs_codebook* cb, const pvs_pca* pca, const void* desc,
+                               int desc_kind, const int64_t* offsets, int64_t n_images, const pvs_norm_params* prm,
+                               float* out, int32_t* out_labels) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(cb, "codebook");
+  PVS_TRY(check_kind(desc_kind));
+  if (n_images < 0) PVS_FAIL(PVS_ERR_INVALID, "negative image count");
+  if (n_images == 0) return PVS_OK;
+  PVS_NEED(offsets, "offsets");
+  PVS_NEED(out, "out");
+  int64_t total = 0;
+  PVS_TRY(host_total(offsets, n_images, &total));
+  if (total > 0) PVS_NEED(desc, "descriptors");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const int d_in = pca ? pca->Din : cb->D;
+  const size_t desc_bytes = (size_t)total * d_in * desc_elem_size(desc_kind);
+  const size_t out_elems = (size_t)n_images * cb->K * cb->D;
+  char* d_x = nullptr;
+  char* d_small = nullptr;
+  float* d_out = nullptr;
+  PVS_TRY(ws_reserve(ctx, 0, desc_bytes, reinterpret_cast<void**>(&d_x)));
+  const size_t off_bytes = (size_t)(n_images + 1) * sizeof(int64_t);
+  const size_t lab_off = (off_bytes + 255) / 256 * 256;
+  PVS_TRY(ws_reserve(ctx, 2, lab_off + (size_t)std::max<int64_t>(total, 1) * sizeof(int32_t) + out_elems * 4 + 256,
+                     reinterpret_cast<void**>(&d_small)));
+  int64_t* d_off = reinterpret_cast<int64_t*>(d_small);
+  int32_t* d_lab = reinterpret_cast<int32_t*>(d_small + lab_off);
+  const size_t out_off = (lab_off + (size_t)std::max<int64_t>(total, 1) * 4 + 255) / 256 * 256;
+  d_out = reinterpret_cast<float*>(d_small + out_off);
+  if (desc_bytes) PVS_HIP(hipMemcpyAsync(d_x, desc, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+  PVS_HIP(hipMemcpyAsync(d_off, offsets, off_bytes, hipMemcpyHostToDevice, ctx->stream));
+  PVS_TRY(pvs_vlad_encode_dev(ctx, cb, pca, d_x, desc_kind, d_off, n_images, total, prm, d_out, d_lab, nullptr));
+  PVS_HIP(hipMemcpyAsync(out, d_out, out_elems * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_labels && total > 0)
+    PVS_HIP(hipMemcpyAsync(out_labels, d_lab, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  return PVS_OK;
+}
+
+// ================================================================================ Fisher / PCA
+PVS_EXPORT int pvs_pca_transform_dev(pvs_ctx* ctx, const pvs_pca* p, const void* d_desc, int desc_kind,
+                                     int64_t total_desc, float* d_out) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(p, "pca");
+  PVS_TRY(check_kind(desc_kind));
+  if (total_desc <= 0) return PVS_OK;
+  PVS_NEED(d_desc, "descriptors");
+  PVS_NEED(d_out, "out");
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_pca(ctx, p, d_desc, desc_kind, total_desc, d_out);
+}
+
+PVS_EXPORT int pvs_gmm_predict_proba_dev(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int desc_kind,
+                                         int64_t total_desc, double* d_resp) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(g, "gmm");
+  PVS_TRY(check_kind(desc_kind));
+  if (total_desc <= 0) return PVS_OK;
+  PVS_NEED(d_desc, "descriptors");
+  PVS_NEED(d_resp, "resp");
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_gmm_posterior(ctx, g, d_desc, desc_kind, g->D, total_desc, d_resp);
+}
+
+PVS_EXPORT int pvs_fisher_encode_dev(pvs_ctx* ctx, const pvs_gmm* g, const pvs_pca* pca, const void* d_desc,
+                                     int desc_kind, const int64_t* d_offsets, int64_t n_images, int64_t total_desc,
+                                     const pvs_norm_params* prm, void* d_out, int out_f64) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(g, "gmm");
+  PVS_TRY(check_kind(desc_kind));
+  PVS_TRY(check_norm(prm));
+  if (n_images < 0 || total_desc < 0) PVS_FAIL(PVS_ERR_INVALID, "negative sizes");
+  if (n_images == 0) return PVS_OK;
+  PVS_NEED(d_offsets, "offsets");
+  PVS_NEED(d_out, "out");
+  if (total_desc > 0) PVS_NEED(d_desc, "descriptors");
+  PVS_HIP(hipSetDevice(ctx->device));
+  int kind = desc_kind, ld = 0;
+  const void* x = d_desc;
+  PVS_TRY(project_if_needed(ctx, pca, g->D, x, kind, total_desc, ld));
+  return launch_fisher(ctx, g, x, kind, ld, d_offsets, n_images, total_desc, *prm, d_out, out_f64);
+}
+
+PVS_EXPORT int pvs_fisher_encode(pvs_ctx* ctx, const pvs_gmm* g, const pvs_pca* pca, const void* desc, int desc_kind,
+                                 const int64_t* offsets, int64_t n_images, const pvs_norm_params* prm, double* out) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(g, "gmm");
+  PVS_TRY(check_kind(desc_kind));
+  if (n_images < 0) PVS_FAIL(PVS_ERR_INVALID, "negative image count");
+  if (n_images == 0) return PVS_OK;
+  PVS_NEED(offsets, "offsets");
+  PVS_NEED(out, "out");
+  int64_t total = 0;
+  PVS_TRY(host_total(offsets, n_images, &total));
+  if (total > 0) PVS_NEED(desc, "descriptors");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const int d_in = pca ? pca->Din : g->D;
+  const size_t desc_bytes = (size_t)total * d_in * desc_elem_size(desc_kind);
+  const size_t out_elems = (size_t)n_images * ((size_t)g->K + 2 * (size_t)g->K * g->D);
+  char* d_x = nullptr;
+  char* d_small = nullptr;
+  PVS_TRY(ws_reserve(ctx, 0, desc_bytes, reinterpret_cast<void**>(&d_x)));
+  const size_t off_bytes = ((size_t)(n_images + 1) * sizeof(int64_t) + 255) / 256 * 256;
+  PVS_TRY(ws_reserve(ctx, 2, off_bytes + out_elems * 8, reinterpret_cast<void**>(&d_small)));
+  int64_t* d_off = reinterpret_cast<int64_t*>(d_small);
+  double* d_out = reinterpret_cast<double*>(d_small + off_bytes);
+  if (desc_bytes) PVS_HIP(hipMemcpyAsync(d_x, desc, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+  PVS_HIP(hipMemcpyAsync(d_off, offsets, (size_t)(n_images + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  PVS_TRY(pvs_fisher_encode_dev(ctx, g, pca, d_x, desc_kind, d_off, n_images, total, prm, d_out, 1));
+  PVS_HIP(hipMemcpyAsync(out, d_out, out_elems * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  return PVS_OK;
+}
+
+// ================================================================================ cosine / top-k
+PVS_EXPORT int pvs_row_inv_norms_dev(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L, float* d_inv) {
+  PVS_NEED(ctx, "ctx");
+  if (rows <= 0) return PVS_OK;
+  PVS_NEED(d_x, "x");
+  PVS_NEED(d_inv, "inv");
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_row_inv_norms(ctx, d_x, rows, L, d_inv);
+}
+
+PVS_EXPORT int pvs_cosine_dev(pvs_ctx* ctx, const float* d_A, int64_t M, const float* d_B, int64_t N, int64_t L,
+                              const float* d_inv_a, const float* d_inv_b, float* d_out, int64_t ldo) {
+  PVS_NEED(ctx, "ctx");
+  if (M <= 0 || N <= 0) return PVS_OK;
+  PVS_NEED(d_A, "A");
+  PVS_NEED(d_B, "B");
+  PVS_NEED(d_out, "out");
+  if (ldo < N) PVS_FAIL(PVS_ERR_INVALID, "cosine: ldo (%lld) < N (%lld)", (long long)ldo, (long long)N);
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_cosine_f32(ctx, d_A, M, d_B, N, L, d_inv_a, d_inv_b, d_out, ldo);
+}
+
+PVS_EXPORT int pvs_cosine(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, int is_f64,
+                          void* out) {
+  PVS_NEED(ctx, "ctx");
+  if (M < 0 || N < 0) PVS_FAIL(PVS_ERR_INVALID, "negative sizes");
+  if (L <= 1) PVS_FAIL(PVS_ERR_INVALID, "Cosine similarity requires at least 2 features. Got %lld features.", (long long)L);
+  if (M == 0 || N == 0) return PVS_OK;
+  PVS_NEED(A, "A");
+  PVS_NEED(B, "B");
+  PVS_NEED(out, "out");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const size_t es = is_f64 ? 8 : 4;
+  const size_t a_bytes = ((size_t)M * L * es + 255) / 256 * 256, b_bytes = ((size_t)N * L * es + 255) / 256 * 256;
+  char* d_in = nullptr;
+  char* d_o = nullptr;
+  const bool same = (A == B && M == N);
+  PVS_TRY(ws_reserve(ctx, 0, a_bytes + (same ? 0 : b_bytes), reinterpret_cast<void**>(&d_in)));
+  const size_t nrm_bytes = ((size_t)(M + N) * 4 + 255) / 256 * 256;
+  PVS_TRY(ws_reserve(ctx, 2, nrm_bytes + (size_t)M * N * es, reinterpret_cast<void**>(&d_o)));
+  PVS_HIP(hipMemcpyAsync(d_in, A, (size_t)M * L * es, hipMemcpyHostToDevice, ctx->stream));
+  char* d_b = d_in;
+  if (!same) {
+    d_b = d_in + a_bytes;
+    PVS_HIP(hipMemcpyAsync(d_b, B, (size_t)N * L * es, hipMemcpyHostToDevice, ctx->stream));
+  }
+  void* d_out = d_o + nrm_bytes;
+  if (is_f64) {
+    PVS_TRY(launch_cosine_f64(ctx, reinterpret_cast<double*>(d_in), M, reinterpret_cast<double*>(d_b), N, L,
+                              reinterpret_cast<double*>(d_out)));
+  } else {
+    float* inva = reinterpret_cast<float*>(d_o);
+    float* invb = inva + M;
+    PVS_TRY(launch_row_inv_norms(ctx, reinterpret_cast<float*>(d_in), M, L, inva));
+    PVS_TRY(launch_row_inv_norms(ctx, reinterpret_cast<float*>(d_b), N, L, invb));
+    PVS_TRY(launch_cosine_f32(ctx, reinterpret_cast<float*>(d_in), M, reinterpret_cast<float*>(d_b), N, L, inva, invb,
+                              reinterpret_cast<float*>(d_out), N));
+  }
+  PVS_HIP(hipMemcpyAsync(out, d_out, (size_t)M * N * es, hipMemcpyDeviceToHost, ctx->stream));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_topk_dev(pvs_ctx* ctx, const float* d_scores, int64_t nq, int64_t ncols, int64_t ld, int k,
+                            int64_t col_offset, int merge, int64_t* d_idx, float* d_val) {
+  PVS_NEED(ctx, "ctx");
+  if (nq <= 0) return PVS_OK;
+  PVS_NEED(d_idx, "idx");
+  PVS_NEED(d_val, "val");
+  if (ncols > 0) PVS_NEED(d_scores, "scores");
+  if (ncols < 0 || ld < ncols || col_offset < 0) PVS_FAIL(PVS_ERR_INVALID, "top-k: bad panel geometry");
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_topk(ctx, d_scores, nq, ncols, ld, k, col_offset, merge, d_idx, d_val);
+}
+
+PVS_EXPORT int pvs_topk_merge_dev(pvs_ctx* ctx, const int64_t* d_idx_lists, const float* d_val_lists, int n_lists,
+                                  int64_t nq, int k, int64_t* d_idx, float* d_val) {
+  PVS_NEED(ctx, "ctx");
+  if (nq <= 0) return PVS_OK;
+  PVS_NEED(d_idx_lists, "idx lists");
+  PVS_NEED(d_val_lists, "val lists");
+  PVS_NEED(d_idx, "idx");
+  PVS_NEED(d_val, "val");
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_topk_merge(ctx, d_idx_lists, d_val_lists, n_lists, nq, k, d_idx, d_val);
+}
+
+PVS_EXPORT int pvs_cosine_topk_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L,
+                                   const float* d_inv_q, const float* d_inv_db, int k, int64_t col_offset, int merge,
+                                   int64_t* d_idx, float* d_val) {
+  PVS_NEED(ctx, "ctx");
+  if (nq <= 0) return PVS_OK;
+  PVS_NEED(d_Q, "Q");
+  PVS_NEED(d_idx, "idx");
+  PVS_NEED(d_val, "val");
+  if (N < 0) PVS_FAIL(PVS_ERR_INVALID, "negative N");
+  PVS_HIP(hipSetDevice(ctx->device));
+  if (N == 0) return launch_topk(ctx, nullptr, nq, 0, 0, k, col_offset, merge, d_idx, d_val);
+  PVS_NEED(d_DB, "DB");
+  // score panel: at most 8192 x 32768 fp32 = 1 GiB, written by the GEMM and consumed by the select
+  const int64_t QT = std::min<int64_t>(nq, 8192), NC = std::min<int64_t>(N, 32768);
+  float* panel = nullptr;
+  PVS_TRY(ws_reserve(ctx, 2, (size_t)QT * NC * sizeof(float), reinterpret_cast<void**>(&panel)));
+  for (int64_t q0 = 0; q0 < nq; q0 += QT) {
+    const int64_t qn = std::min(QT, nq - q0);
+    for (int64_t c0 = 0; c0 < N; c0 += NC) {
+      const int64_t cn = std::min(NC, N - c0);
+      PVS_TRY(launch_cosine_f32(ctx, d_Q + q0 * L, qn, d_DB + c0 * L, cn, L, d_inv_q ? d_inv_q + q0 : nullptr,
+                                d_inv_db ? d_inv_db + c0 : nullptr, panel, cn));
+      PVS_TRY(launch_topk(ctx, panel, qn, cn, cn, k, col_offset + c0, (merge || c0 > 0) ? 1 : 0, d_idx + q0 * k,
+                          d_val + q0 * k));
+    }
+  }
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L, int k,
+                               int64_t* out_idx, float* out_val) {
+  PVS_NEED(ctx, "ctx");
+  if (nq <= 0) return PVS_OK;
+  if (L <= 1) PVS_FAIL(PVS_ERR_INVALID, "Cosine similarity requires at least 2 features. Got %lld features.", (long long)L);
+  PVS_NEED(Q, "Q");
+  PVS_NEED(DB, "DB");
+  PVS_NEED(out_idx, "idx");
+  PVS_NEED(out_val, "val");
+  if (N <= 0) PVS_FAIL(PVS_ERR_INVALID, "empty database");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const bool same = (Q == DB && nq == N);
+  const size_t q_bytes = ((size_t)nq * L * 4 + 255) / 256 * 256, db_bytes = ((size_t)N * L * 4 + 255) / 256 * 256;
+  char* d_in = nullptr;
+  char* d_s = nullptr;
+  PVS_TRY(ws_reserve(ctx, 0, q_bytes + (same ? 0 : db_bytes), reinterpret_cast<void**>(&d_in)));
+  const size_t nrm = ((size_t)(nq + N) * 4 + 255) / 256 * 256, idxb = ((size_t)nq * k * 8 + 255) / 256 * 256;
+  PVS_TRY(ws_reserve(ctx, 1, nrm + idxb + (size_t)nq * k * 4, reinterpret_cast<void**>(&d_s)));
+  float* dq = reinterpret_cast<float*>(d_in);
+  float* ddb = same ? dq : reinterpret_cast<float*>(d_in + q_bytes);
+  PVS_HIP(hipMemcpyAsync(dq, Q, (size_t)nq * L * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (!same) PVS_HIP(hipMemcpyAsync(ddb, DB, (size_t)N * L * 4, hipMemcpyHostToDevice, ctx->stream));
+  float* invq = reinterpret_cast<float*>(d_s);
+  float* invd = invq + nq;
+  int64_t* d_idx = reinterpret_cast<int64_t*>(d_s + nrm);
+  float* d_val = reinterpret_cast<float*>(d_s + nrm + idxb);
+  PVS_TRY(launch_row_inv_norms(ctx, dq, nq, L, invq));
+  PVS_TRY(launch_row_inv_norms(ctx, ddb, N, L, invd));
+  PVS_TRY(pvs_cosine_topk_dev(ctx, dq, nq, ddb, N, L, invq, invd, k, 0, 0, d_idx, d_val));
+  PVS_HIP(hipMemcpyAsync(out_idx, d_idx, (size_t)nq * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PVS_HIP(hipMemcpyAsync(out_val, d_val, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  return PVS_OK;
+}
+
+// ================================================================================ timers
+PVS_EXPORT int pvs_timers_enable(pvs_ctx* ctx, int on) {
+  PVS_NEED(ctx, "ctx");
+  PVS_TRY(drain_timers(ctx));
+  ctx->timers_on = on != 0;
+  return PVS_OK;
+}
+PVS_EXPORT int pvs_timers_reset(pvs_ctx* ctx) {
+  PVS_NEED(ctx, "ctx");
+  PVS_TRY(drain_timers(ctx));
+  for (int i = 0; i < PVS_TIMER_SLOTS; ++i) {
+    ctx->t_total[i] = 0;
+    ctx->t_count[i] = 0;
+  }
+  return PVS_OK;
+}
+PVS_EXPORT int pvs_timers_read(pvs_ctx* ctx, int which, double* total_ms, int64_t* launches) {
+  PVS_NEED(ctx, "ctx");
+  if (which < 0 || which >= PVS_TIMER_SLOTS) PVS_FAIL(PVS_ERR_INVALID, "timer slot %d out of range", which);
+  PVS_TRY(drain_timers(ctx));
+  if (total_ms) *total_ms = ctx->t_total[which];
+  if (launches) *launches = ctx->t_count[which];
+  return PVS_OK;
+}

@@ -1,0 +1,139 @@
+// Internal definitions shared by the HIP translation units of libpvsim_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/pvsim.h"
+
+#define PVS_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace pvs {
+
+void set_error(const char* fmt, ...);
+
+#define PVS_FAIL(code, ...)        \
+  do {                             \
+    ::pvs::set_error(__VA_ARGS__); \
+    return (code);                 \
+  } while (0)
+
+#define PVS_HIP(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e__ = (expr);                                                             \
+    if (e__ != hipSuccess) {                                                             \
+      ::pvs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                       __LINE__);                                                        \
+      return e__ == hipErrorOutOfMemory ? PVS_ERR_OOM : PVS_ERR_NO_DEVICE;               \
+    }                                                                                    \
+  } while (0)
+
+#define PVS_TRY(expr)                 \
+  do {                                \
+    int s__ = (expr);                 \
+    if (s__ != PVS_OK) return s__;    \
+  } while (0)
+
+constexpr int WAVE = 64;
+
+enum TimerSlot { T_ASSIGN = 0, T_AGGREGATE = 1, T_GEMM = 2, T_TOPK = 3, T_FPOST = 4, T_FMOM = 5, T_MISC = 6 };
+
+struct TimerRec {
+  hipEvent_t a, b;
+  int slot;
+};
+
+}  // namespace pvs
+
+struct pvs_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  int num_cu = 256;
+  // grow-only scratch areas (device)
+  // 0 host-API input staging, 1 scratch (labels, tables, responsibilities), 2 host-API outputs / score panel,
+  // 3 PCA projections, 4 materialised RootSIFT rows
+  static constexpr int NWS = 5;
+  void* ws[NWS] = {};
+  size_t ws_bytes[NWS] = {};
+  // timers
+  bool timers_on = false;
+  std::vector<pvs::TimerRec> pending;
+  double t_total[PVS_TIMER_SLOTS] = {0};
+  int64_t t_count[PVS_TIMER_SLOTS] = {0};
+};
+
+struct pvs_codebook {
+  int K = 0, D = 0;
+  int K_pad = 0, D_pad = 0;  // K_pad multiple of 32, D_pad multiple of 8 (zero / +inf padded)
+  float* d_cent = nullptr;   // [K][D]     exact user layout (for the aggregate step)
+  float* d_cpad = nullptr;   // [K_pad][D_pad] zero padded (MFMA operand)
+  float* d_cnorm = nullptr;  // [K_pad]   ||c||^2, +inf on padded clusters
+};
+
+struct pvs_gmm {
+  int K = 0, D = 0;
+  double* d_w = nullptr;     // [K]
+  double* d_mu = nullptr;    // [K][D]
+  double* d_cov = nullptr;   // [K][D]
+  // derived, fp64 (sklearn/mixture/_gaussian_mixture.py:495-512)
+  double* d_prec = nullptr;  // [K][D]  1/cov
+  double* d_mup = nullptr;   // [K][D]  mu/cov
+  double* d_const = nullptr; // [K]     -0.5*(D log 2pi + sum mu^2/cov) + sum log(1/sqrt(cov)) + log w
+};
+
+struct pvs_pca {
+  int C = 0, Din = 0;
+  float* d_comp = nullptr;   // [C][Din]
+  float* d_off = nullptr;    // [C]  mean @ components^T
+};
+
+namespace pvs {
+
+int ws_reserve(pvs_ctx* ctx, int which, size_t bytes, void** out);
+
+struct ScopedTimer {
+  pvs_ctx* ctx;
+  int slot;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(pvs_ctx* c, int s) : ctx(c), slot(s) {
+    if (ctx->timers_on) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, ctx->stream);
+    }
+  }
+  ~ScopedTimer() {
+    if (a) {
+      (void)hipEventRecord(b, ctx->stream);
+      ctx->pending.push_back({a, b, slot});
+    }
+  }
+};
+
+// ---- launchers implemented in the kernel translation units (all enqueue on ctx->stream)
+int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int64_t total, int ld,
+                  int32_t* d_labels);
+int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int ld,
+                          const int64_t* d_offsets, int64_t n_images, const int32_t* d_labels,
+                          const pvs_norm_params& prm, float* d_out, float* d_inv_norm);
+int launch_row_inv_norms(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L, float* d_inv);
+int launch_cosine_f32(pvs_ctx* ctx, const float* A, int64_t M, const float* B, int64_t N, int64_t L,
+                      const float* inva, const float* invb, float* out, int64_t ldo);
+int launch_cosine_f64(pvs_ctx* ctx, const double* A, int64_t M, const double* B, int64_t N, int64_t L, double* out);
+int launch_topk(pvs_ctx* ctx, const float* scores, int64_t nq, int64_t ncols, int64_t ld, int k,
+                int64_t col_offset, int merge, int64_t* d_idx, float* d_val);
+int launch_topk_merge(pvs_ctx* ctx, const int64_t* idx_lists, const float* val_lists, int n_lists, int64_t nq,
+                      int k, int64_t* d_idx, float* d_val);
+int launch_pca(pvs_ctx* ctx, const pvs_pca* p, const void* d_desc, int kind, int64_t total, float* d_out);
+int launch_gmm_posterior(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int kind, int ld, int64_t total,
+                         double* d_resp);
+int launch_fisher(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int kind, int ld, const int64_t* d_offsets,
+                  int64_t n_images, int64_t total, const pvs_norm_params& prm, void* d_out, int out_f64);
+
+}  // namespace pvs

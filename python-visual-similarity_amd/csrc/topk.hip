@@ -1,0 +1,214 @@
+// K7 top-k: per query row, the first k entries of np.argsort(-scores)  (pyvisim/eval.py:37-43,75-80,131-132).
+//
+// Order is total and deterministic: (score descending, index ascending); NaN scores rank last (as NumPy's
+// sort puts NaN at the end of -scores).  The reference uses a non-stable argsort, so its tie order is
+// unspecified; on tie-free rows the lists are identical.
+//
+// One workgroup per row.  Every candidate becomes a 64-bit key  mono(score) << 32 | ~index  (all keys of a
+// row are distinct, larger key = better).  A panel is consumed in chunks of 8192 columns held in registers
+// together with the running list; the k best are found by an MSB-first 8-bit radix SELECT (LDS histogram,
+// early exit when the pivot bin is taken whole), compacted, and only the final list is sorted (bitonic).
+#include "common.hpp"
+
+namespace pvs {
+
+constexpr int TK_THREADS = 256;
+constexpr int TK_ITEMS = 32;                      // columns per thread per chunk
+constexpr int TK_CHUNK = TK_THREADS * TK_ITEMS;   // 8192
+constexpr int TK_KMAX = 1024;
+constexpr int TK_RUN = TK_KMAX / TK_THREADS;      // running-list keys per thread
+
+__device__ __forceinline__ uint32_t mono_f32(float f) {
+  if (f != f) return 1u;                           // NaN: below every number (-inf maps to 0x007fffff)
+  f += 0.0f;                                       // -0 -> +0 (equal scores must tie)
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unmono_f32(uint32_t m) {
+  if (m == 1u) return __uint_as_float(0x7fc00000u);
+  return __uint_as_float((m & 0x80000000u) ? (m & 0x7fffffffu) : ~m);
+}
+__device__ __forceinline__ uint64_t make_key(float v, uint32_t idx) {
+  return ((uint64_t)mono_f32(v) << 32) | (uint64_t)(~idx);
+}
+
+struct TopkArgs {
+  const float* scores;      // panel mode: [nq][ld];   list mode: val lists [n_lists][nq][k]
+  const int64_t* idx_lists; // list mode only: [n_lists][nq][k]
+  int64_t nq, ncols, ld;
+  int k;
+  int64_t col_offset;
+  int merge;
+  int n_lists;              // > 0 selects list mode (ncols = n_lists * k)
+  int64_t* idx;             // [nq][k]
+  float* val;               // [nq][k]
+};
+
+// block-wide inclusive scan of one int per thread (256 threads); tmp: LDS int[4]
+__device__ __forceinline__ int block_incl_scan(int v, int* tmp, int lane, int wave) {
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) tmp[wave] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wave; ++w) off += tmp[w];
+  __syncthreads();
+  return incl + off;
+}
+
+__global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkArgs a) {
+  __shared__ uint64_t run[2][TK_KMAX];
+  __shared__ int hist[256];
+  __shared__ int stmp[4];
+  __shared__ int s_bin, s_above, s_cnt;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t q = blockIdx.x;
+  const int k = a.k;
+  int cur = 0;
+  int run_count = 0;
+
+  // ---- running list from a previous panel
+  if (a.merge) {
+    int mine = 0;
+    for (int r = tid; r < k; r += TK_THREADS) mine += a.idx[q * k + r] >= 0;
+    const int incl = block_incl_scan(mine, stmp, lane, wave);
+    int pos = incl - mine;
+    for (int r = tid; r < k; r += TK_THREADS) {
+      const int64_t id = a.idx[q * k + r];
+      if (id >= 0) run[cur][pos++] = make_key(a.val[q * k + r], (uint32_t)id);
+    }
+    if (tid == TK_THREADS - 1) s_cnt = incl;
+    __syncthreads();
+    run_count = s_cnt;
+    __syncthreads();
+  }
+
+  for (int64_t c0 = 0; c0 < a.ncols; c0 += TK_CHUNK) {
+    uint64_t key[TK_ITEMS + TK_RUN];
+    int nvalid = 0;
+#pragma unroll
+    for (int it = 0; it < TK_ITEMS; ++it) {
+      const int64_t c = c0 + (int64_t)it * TK_THREADS + tid;
+      key[it] = 0ull;
+      if (c < a.ncols) {
+        if (a.n_lists > 0) {
+          const int64_t l = c / k, r = c - l * k;
+          const int64_t off = (l * a.nq + q) * k + r;
+          const int64_t id = a.idx_lists[off];
+          if (id >= 0) { key[it] = make_key(a.scores[off], (uint32_t)id); ++nvalid; }
+        } else {
+          key[it] = make_key(a.scores[q * a.ld + c], (uint32_t)(a.col_offset + c));
+          ++nvalid;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TK_RUN; ++r) {
+      const int p = r * TK_THREADS + tid;
+      key[TK_ITEMS + r] = p < run_count ? run[cur][p] : 0ull;
+    }
+    const int total = block_incl_scan(nvalid, stmp, lane, wave);  // inclusive; last thread holds the sum
+    if (tid == TK_THREADS - 1) s_cnt = total + run_count;
+    __syncthreads();
+    const int T = s_cnt;
+    __syncthreads();
+
+    uint64_t prefix = 0ull, mask = 0ull;
+    if (T > k) {
+      int need = k;
+      for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < TK_ITEMS + TK_RUN; ++it)
+          if ((key[it] & mask) == prefix && key[it] != 0ull) atomicAdd(&hist[(int)((key[it] >> shift) & 0xffull)], 1);
+        __syncthreads();
+        const int hv = hist[255 - tid];                  // thread t owns bin 255-t: scan from the top bin down
+        const int incl = block_incl_scan(hv, stmp, lane, wave);
+        if (incl >= need && incl - hv < need) { s_bin = 255 - tid; s_above = incl - hv; }
+        __syncthreads();
+        const int bin = s_bin;
+        need -= s_above;
+        prefix |= (uint64_t)bin << shift;
+        mask |= 0xffull << shift;
+        const bool whole = hist[bin] == need;            // pivot bin is taken whole: selection is decided
+        __syncthreads();
+        if (whole) break;
+      }
+    }
+    // ---- compact the selected keys into the other buffer (T <= k: everything valid is selected)
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < TK_ITEMS + TK_RUN; ++it) {
+      if (key[it] != 0ull && (key[it] & mask) >= prefix) {
+        const int p = atomicAdd(&s_cnt, 1);
+        if (p < TK_KMAX) run[cur ^ 1][p] = key[it];
+      }
+    }
+    __syncthreads();
+    run_count = min(s_cnt, TK_KMAX);  // == k unless the inputs held duplicate (score, index) pairs
+    cur ^= 1;
+    __syncthreads();
+  }
+
+  // ---- sort the final list descending (bitonic, padded with 0 = worst)
+  int P = 1;
+  while (P < run_count) P <<= 1;
+  for (int p = run_count + tid; p < P; p += TK_THREADS) run[cur][p] = 0ull;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += TK_THREADS) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const uint64_t x = run[cur][lo], y = run[cur][hi];
+        if ((x < y) == desc) { run[cur][lo] = y; run[cur][hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int r = tid; r < k; r += TK_THREADS) {
+    if (r < run_count) {  // run_count may exceed k only with duplicate inputs; the sort keeps the best first
+      const uint64_t kk = run[cur][r];
+      a.idx[q * k + r] = (int64_t)(uint32_t)(~(uint32_t)(kk & 0xffffffffull));
+      a.val[q * k + r] = unmono_f32((uint32_t)(kk >> 32));
+    } else {
+      a.idx[q * k + r] = -1;
+      a.val[q * k + r] = -INFINITY;
+    }
+  }
+}
+
+static int launch_topk_impl(pvs_ctx* ctx, const TopkArgs& a) {
+  if (a.nq <= 0) return PVS_OK;
+  if (a.k < 1 || a.k > TK_KMAX) PVS_FAIL(PVS_ERR_UNSUPPORTED, "top-k: k must be in [1, %d] (got %d)", TK_KMAX, a.k);
+  if (a.nq > 0x7fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "top-k: too many query rows for one launch");
+  if (a.col_offset + a.ncols > 0xfffffffeLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "top-k: column index exceeds 32 bits");
+  ScopedTimer tm(ctx, T_TOPK);
+  hipLaunchKernelGGL(topk_kernel, dim3((unsigned)a.nq), dim3(TK_THREADS), 0, ctx->stream, a);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+int launch_topk(pvs_ctx* ctx, const float* scores, int64_t nq, int64_t ncols, int64_t ld, int k, int64_t col_offset,
+                int merge, int64_t* d_idx, float* d_val) {
+  TopkArgs a{scores, nullptr, nq, ncols, ld, k, col_offset, merge, 0, d_idx, d_val};
+  return launch_topk_impl(ctx, a);
+}
+
+int launch_topk_merge(pvs_ctx* ctx, const int64_t* idx_lists, const float* val_lists, int n_lists, int64_t nq, int k,
+                      int64_t* d_idx, float* d_val) {
+  if (n_lists < 1) PVS_FAIL(PVS_ERR_INVALID, "top-k merge: n_lists must be >= 1");
+  TopkArgs a{val_lists, idx_lists, nq, (int64_t)n_lists * k, 0, k, 0, 0, n_lists, d_idx, d_val};
+  return launch_topk_impl(ctx, a);
+}
+
+}  // namespace pvs

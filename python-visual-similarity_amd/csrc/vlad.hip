@@ -1,0 +1,517 @@
+// VLAD encode on gfx950: K1 assign (KMeans.predict) and K2+K3 aggregate + normalise.
+//
+// Reference semantics (paths relative to the reference root):
+//   K1  pyvisim/encoders/vlad.py:95 -> sklearn/cluster/_k_means_lloyd.pyx:168-218
+//         label_i = argmin_j (||c_j||^2 - 2 x_i.c_j), fp32, strict '<' => first minimum wins
+//   K2  vlad.py:98-104   V[label_i] += (x_i - c_label_i)  sequentially in descriptor order, fp32
+//   K3  vlad.py:106-111  sign(V)|V|^p ; per-cluster row norm + eps ; divide ; k-major flatten
+//
+// K1 is exact-fp32 GEMM shaped (2*n*K*D flop): v_mfma_f32_32x32x2_f32, centroid block resident in LDS,
+// descriptor rows streamed HBM -> registers.  K2/K3 is HBM/latency bound: per image a stable counting
+// sort of the labels in LDS, then one lane-group per cluster sums its descriptors IN DESCRIPTOR ORDER
+// (bit-identical to the reference's loop given equal labels; no float atomics, run-to-run reproducible).
+#include "common.hpp"
+#include "desc_load.hpp"
+
+namespace pvs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ======================================================================================= K1 assign
+struct AssignArgs {
+  const void* X;
+  int64_t total;
+  int D, ld;
+  const float* Cpad;   // [K_pad][D_pad], zero padded
+  const float* cnorm;  // [K_pad], +inf on padded clusters
+  int K_pad, D_pad;
+  int32_t* labels;
+};
+
+constexpr int ASSIGN_THREADS = 512;                 // 8 waves, 2 per SIMD
+constexpr int ASSIGN_ROWS = (ASSIGN_THREADS / 64) * 32;  // 256 descriptors per workgroup step
+constexpr int ASSIGN_DCHUNK = 128;                  // dims resident in LDS / registers at a time
+
+// Operand roles: MFMA "A" = centroids (rows i = cluster within a 32-tile, from LDS),
+//                MFMA "B" = descriptors (cols j = lane & 31, from registers).
+// D[i][j] lands with col j on the lane and 16 rows in registers, so the argmin over clusters is
+// lane-local except for one exchange between the two half-waves.
+// K-slot mapping: lane (., h = lane>>5) feeds dims 8t+4h .. 8t+4h+3 to the four k-steps of step t; the
+// same permutation is applied to both operands, so the sum is over all dims.
+template <int NT, int KIND, bool VEC>
+__global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign_kernel(AssignArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CB = 32 * NT;
+  const int cw_max = a.D_pad < ASSIGN_DCHUNK ? a.D_pad : ASSIGN_DCHUNK;
+  const int stride = cw_max + 4;  // +16 B per row: ds_read_b128 of 16 consecutive rows is conflict-free
+  float* lds_c = reinterpret_cast<float*>(smem);
+  float* lds_n = lds_c + CB * stride;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int ncb = a.K_pad / CB;
+  const int nsc = (a.D_pad + ASSIGN_DCHUNK - 1) / ASSIGN_DCHUNK;
+  const bool restage = (ncb * nsc) > 1;
+  const int64_t nblocks = (a.total + ASSIGN_ROWS - 1) / ASSIGN_ROWS;
+
+  auto stage = [&](int cb, int sc) {
+    const int cw = min(ASSIGN_DCHUNK, a.D_pad - sc * ASSIGN_DCHUNK);
+    const int c4n = cw >> 2;
+    for (int idx = threadIdx.x; idx < CB * c4n; idx += ASSIGN_THREADS) {
+      const int r = idx / c4n, c4 = idx - r * c4n;
+      const float4 v = *reinterpret_cast<const float4*>(a.Cpad + (int64_t)(cb * CB + r) * a.D_pad +
+                                                        sc * ASSIGN_DCHUNK + 4 * c4);
+      *reinterpret_cast<float4*>(lds_c + r * stride + 4 * c4) = v;
+    }
+    for (int idx = threadIdx.x; idx < CB; idx += ASSIGN_THREADS) lds_n[idx] = a.cnorm[cb * CB + idx];
+  };
+
+  if (!restage) {
+    stage(0, 0);
+    __syncthreads();
+  }
+
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int64_t row = blk * ASSIGN_ROWS + wave * 32 + j;
+    const bool rvalid = row < a.total;
+    float best = INFINITY;
+    int bidx = 0;
+
+    for (int cb = 0; cb < ncb; ++cb) {
+      f32x16 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+      for (int sc = 0; sc < nsc; ++sc) {
+        if (restage) {
+          __syncthreads();
+          stage(cb, sc);
+          __syncthreads();
+        }
+        const int dc = sc * ASSIGN_DCHUNK;
+        const int nt = min(ASSIGN_DCHUNK, a.D_pad - dc) >> 3;
+
+        // ---- descriptor fragment: 16 x float4 = this lane's half of a 128-dim slab of its row
+        float4 xb[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          xb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (t < nt) {
+            const int d = dc + 8 * t + 4 * h;
+            if constexpr (VEC) {
+              if (rvalid && d < a.D) xb[t] = load4<KIND>(a.X, row, a.ld, d);
+            } else {
+              if (rvalid) {
+                if (d + 0 < a.D) xb[t].x = load1<KIND>(a.X, row, a.ld, d + 0);
+                if (d + 1 < a.D) xb[t].y = load1<KIND>(a.X, row, a.ld, d + 1);
+                if (d + 2 < a.D) xb[t].z = load1<KIND>(a.X, row, a.ld, d + 2);
+                if (d + 3 < a.D) xb[t].w = load1<KIND>(a.X, row, a.ld, d + 3);
+              }
+            }
+          }
+        }
+        if constexpr (DescTraits<KIND>::rootsift) {
+          // host guarantees D <= 128 (one slab) for the RootSIFT kinds
+          float s = 0.f;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) s += (xb[t].x + xb[t].y) + (xb[t].z + xb[t].w);
+          s += __shfl_xor(s, 32, 64);
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            xb[t].x = rootsift_apply(xb[t].x, s);
+            xb[t].y = rootsift_apply(xb[t].y, s);
+            xb[t].z = rootsift_apply(xb[t].z, s);
+            xb[t].w = rootsift_apply(xb[t].w, s);
+          }
+        }
+
+        // ---- distance tile: NT x (32 clusters x 32 descriptors), exact fp32 MFMA
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          if (t < nt) {
+#pragma unroll
+            for (int tile = 0; tile < NT; ++tile) {
+              const float4 c4 =
+                  *reinterpret_cast<const float4*>(lds_c + (32 * tile + j) * stride + 8 * t + 4 * h);
+              acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.x, xb[t].x, acc[tile], 0, 0, 0);
+              acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.y, xb[t].y, acc[tile], 0, 0, 0);
+              acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.z, xb[t].z, acc[tile], 0, 0, 0);
+              acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.w, xb[t].w, acc[tile], 0, 0, 0);
+            }
+          }
+        }
+      }  // sc
+
+      // ---- lane-local argmin in ascending cluster order (strict '<' keeps the first minimum)
+#pragma unroll
+      for (int tile = 0; tile < NT; ++tile) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int r0 = 32 * tile + 8 * g + 4 * h;  // C/D layout: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+          const float4 cn = *reinterpret_cast<const float4*>(lds_n + r0);
+          const float v0 = fmaf(-2.f, acc[tile][4 * g + 0], cn.x);
+          const float v1 = fmaf(-2.f, acc[tile][4 * g + 1], cn.y);
+          const float v2 = fmaf(-2.f, acc[tile][4 * g + 2], cn.z);
+          const float v3 = fmaf(-2.f, acc[tile][4 * g + 3], cn.w);
+          const int kb = cb * CB + r0;
+          if (v0 < best) { best = v0; bidx = kb + 0; }
+          if (v1 < best) { best = v1; bidx = kb + 1; }
+          if (v2 < best) { best = v2; bidx = kb + 2; }
+          if (v3 < best) { best = v3; bidx = kb + 3; }
+        }
+      }
+    }  // cb
+
+    // the two half-waves hold interleaved cluster subsets of the same descriptor
+    const float oval = __shfl_xor(best, 32, 64);
+    const int oidx = __shfl_xor(bidx, 32, 64);
+    if (oval < best || (oval == best && oidx < bidx)) bidx = oidx;
+    if (h == 0 && rvalid) a.labels[row] = bidx;
+  }
+}
+
+template <int NT, int KIND>
+static int launch_assign_nt(pvs_ctx* ctx, const AssignArgs& a, bool vec, size_t lds, int grid) {
+  auto kv = assign_kernel<NT, KIND, true>;
+  auto ks = assign_kernel<NT, KIND, false>;
+  auto k = vec ? kv : ks;
+  PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds));
+  hipLaunchKernelGGL(k, dim3(grid), dim3(ASSIGN_THREADS), lds, ctx->stream, a);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+template <int KIND>
+static int launch_assign_kind(pvs_ctx* ctx, const AssignArgs& a, int nt, bool vec, size_t lds, int grid) {
+  switch (nt) {
+    case 8: return launch_assign_nt<8, KIND>(ctx, a, vec, lds, grid);
+    case 4: return launch_assign_nt<4, KIND>(ctx, a, vec, lds, grid);
+    case 2: return launch_assign_nt<2, KIND>(ctx, a, vec, lds, grid);
+    default: return launch_assign_nt<1, KIND>(ctx, a, vec, lds, grid);
+  }
+}
+
+int assign_tiles_for(int K) {
+  const int k32 = (K + 31) / 32 * 32;
+  return k32 > 128 ? 8 : (k32 > 64 ? 4 : (k32 > 32 ? 2 : 1));
+}
+
+int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int64_t total, int ld,
+                  int32_t* d_labels) {
+  if (total <= 0) return PVS_OK;
+  const bool rs = kind != PVS_DESC_F32;
+  if (rs && cb->D > ASSIGN_DCHUNK)
+    PVS_FAIL(PVS_ERR_UNSUPPORTED, "fused RootSIFT needs D <= %d (got %d)", ASSIGN_DCHUNK, cb->D);
+  const int nt = assign_tiles_for(cb->K);
+  if (cb->K_pad % (32 * nt) != 0) PVS_FAIL(PVS_ERR_INVALID, "codebook padding does not match the tile count");
+  AssignArgs a{d_desc, total, cb->D, ld, cb->d_cpad, cb->d_cnorm, cb->K_pad, cb->D_pad, d_labels};
+  const int esz = kind == PVS_DESC_U8_ROOTSIFT ? 1 : 4;
+  // vector path: rows and 4-element groups are 16-B (f32) / 4-B (u8) aligned
+  const bool vec = (cb->D % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_desc) % (4 * esz)) == 0);
+  const int cw = cb->D_pad < ASSIGN_DCHUNK ? cb->D_pad : ASSIGN_DCHUNK;
+  const size_t lds = (size_t)(32 * nt) * (cw + 4) * 4 + (size_t)(32 * nt) * 4;
+  const int64_t nblocks = (total + ASSIGN_ROWS - 1) / ASSIGN_ROWS;
+  const int grid = (int)(nblocks < ctx->num_cu ? nblocks : ctx->num_cu);
+  ScopedTimer tm(ctx, T_ASSIGN);
+  switch (kind) {
+    case PVS_DESC_F32: return launch_assign_kind<PVS_DESC_F32>(ctx, a, nt, vec, lds, grid);
+    case PVS_DESC_F32_ROOTSIFT: return launch_assign_kind<PVS_DESC_F32_ROOTSIFT>(ctx, a, nt, vec, lds, grid);
+    case PVS_DESC_U8_ROOTSIFT: return launch_assign_kind<PVS_DESC_U8_ROOTSIFT>(ctx, a, nt, vec, lds, grid);
+    default: PVS_FAIL(PVS_ERR_INVALID, "unknown descriptor kind %d", kind);
+  }
+}
+
+// =============================================================================== K2+K3 aggregate
+struct AggArgs {
+  const void* X;
+  int D, ld;
+  const int64_t* offsets;  // [n_images+1]
+  const int32_t* labels;   // [total]
+  const float* cent;       // [K][D]
+  int K;
+  float power, eps;
+  int norm_mode;           // 0: general p, 1: L1, 2: L2, 3: +inf
+  float norm_p;
+  float* out;              // [n_images][K*D]
+  float* inv_norm;         // [n_images] or null
+};
+
+constexpr int AGG_THREADS = 256;
+constexpr int AGG_WAVES = AGG_THREADS / 64;
+constexpr int AGG_CHUNK = 4096;  // descriptors sorted per pass (u16 indices in LDS)
+
+__device__ __forceinline__ float power_norm(float v, float p) {
+  // np.sign(v) * np.abs(v) ** p  (vlad.py:106); p == 1 and p == 0.5 take exact paths
+  if (p == 1.f) return v;
+  const float a = fabsf(v);
+  const float m = (p == 0.5f) ? sqrtf(a) : powf(a, p);
+  return v > 0.f ? m : (v < 0.f ? -m : (v == 0.f ? 0.f * m : v));
+}
+
+__device__ __forceinline__ float norm_accum(float v, int mode, float p) {
+  const float a = fabsf(v);
+  return mode == 2 ? v * v : (mode == 1 ? a : (mode == 3 ? a : powf(a, p)));
+}
+
+// One workgroup per image.  GROUP lanes cooperate on one cluster row; each lane owns NREG vectors of
+// VW consecutive dims: dims (r*GROUP + gl)*VW ... for r < NREG.
+template <int KIND, int GROUP, int VW, int NREG>
+__global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int K = a.K, D = a.D;
+  int* hist = reinterpret_cast<int*>(smem);              // [AGG_WAVES][K]  counts, then cursors
+  int* start = hist + AGG_WAVES * K;                     // [K+1]
+  float* rowsq = reinterpret_cast<float*>(start + K + 1);  // [K]
+  int* scan_tmp = reinterpret_cast<int*>(rowsq + K);       // [AGG_WAVES] (all LDS stays in the dynamic region)
+  uint16_t* order = reinterpret_cast<uint16_t*>(scan_tmp + AGG_WAVES);  // [AGG_CHUNK]
+
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = a.offsets[img];
+  const int64_t n = a.offsets[img + 1] - row0;
+  float* out_img = a.out + (int64_t)img * K * D;
+
+  constexpr int NGROUPS = AGG_THREADS / GROUP;
+  const int grp = tid / GROUP, gl = tid % GROUP;
+  int kbits = 0;
+  while ((1 << kbits) < K) ++kbits;
+
+  const int64_t nchunks = n > 0 ? (n + AGG_CHUNK - 1) / AGG_CHUNK : 1;
+  for (int64_t ch = 0; ch < nchunks; ++ch) {
+    const int64_t cbase = row0 + ch * AGG_CHUNK;
+    const int cn = (int)min((int64_t)AGG_CHUNK, n - ch * AGG_CHUNK);  // may be 0 for an empty image
+    const bool last = (ch == nchunks - 1);
+
+    // ---- 1. per-wave histograms (integer LDS atomics: order independent)
+    for (int i = tid; i < AGG_WAVES * K; i += AGG_THREADS) hist[i] = 0;
+    __syncthreads();
+    const int per_wave = (cn + AGG_WAVES - 1) / AGG_WAVES;
+    const int wbeg = min(cn, wave * per_wave), wend = min(cn, wbeg + per_wave);
+    for (int i = wbeg + lane; i < wend; i += 64) atomicAdd(&hist[wave * K + a.labels[cbase + i]], 1);
+    __syncthreads();
+
+    // ---- 2. exclusive scan in (cluster major, wave minor) order -> start[k], cursors
+    {
+      int carry = 0;  // running total of all clusters before this tile of 256
+      for (int k0 = 0; k0 < K; k0 += AGG_THREADS) {
+        const int k = k0 + tid;
+        int c[AGG_WAVES], tot = 0;
+#pragma unroll
+        for (int w = 0; w < AGG_WAVES; ++w) {
+          c[w] = k < K ? hist[w * K + k] : 0;
+          tot += c[w];
+        }
+        // inclusive scan of tot across the 256 threads
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += o;
+        }
+        if (lane == 63) scan_tmp[wave] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += scan_tmp[w];
+        int tile_total = 0;
+        for (int w = 0; w < AGG_WAVES; ++w) tile_total += scan_tmp[w];
+        int excl = carry + wave_off + incl - tot;
+        if (k < K) {
+          start[k] = excl;
+#pragma unroll
+          for (int w = 0; w < AGG_WAVES; ++w) {
+            hist[w * K + k] = excl;
+            excl += c[w];
+          }
+        }
+        carry += tile_total;
+        __syncthreads();
+      }
+      if (tid == 0) start[K] = cn;
+    }
+    __syncthreads();
+
+    // ---- 3. stable placement: each wave walks its contiguous quarter in order, 64 at a time;
+    //         same-label lanes are found with kbits ballots (match-any), rank = #lower lanes
+    for (int i0 = wbeg; i0 < wend; i0 += 64) {
+      const int i = i0 + lane;
+      const bool v = i < wend;
+      const int lab = v ? a.labels[cbase + i] : -1;
+      unsigned long long peers = __ballot(v);
+      for (int b = 0; b < kbits; ++b) {
+        const unsigned long long bal = __ballot((lab >> b) & 1);
+        peers &= ((lab >> b) & 1) ? bal : ~bal;
+      }
+      if (v) {
+        const unsigned long long lower = peers & ((1ull << lane) - 1ull);
+        const int rank = __popcll(lower);
+        const int basepos = hist[wave * K + lab];
+        order[basepos + rank] = (uint16_t)i;
+        // the highest peer lane advances the cursor after every peer has read it (one wave: lockstep)
+        if ((peers >> lane) == 1ull) hist[wave * K + lab] = basepos + rank + 1;
+      }
+    }
+    __syncthreads();
+
+    // ---- 4. one lane-group per cluster: sequential fp32 sum of (x - c) in descriptor order
+    for (int k = grp; k < K; k += NGROUPS) {
+      const int s = start[k], e = start[k + 1];
+      float acc[NREG][VW], c[NREG][VW];
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) {
+        const int d0 = (r * GROUP + gl) * VW;
+#pragma unroll
+        for (int q = 0; q < VW; ++q) {
+          const bool in = d0 + q < D;
+          c[r][q] = in ? a.cent[(int64_t)k * D + d0 + q] : 0.f;
+          acc[r][q] = (ch > 0 && in) ? out_img[(int64_t)k * D + d0 + q] : 0.f;  // continue a long image
+        }
+      }
+      for (int p = s; p < e; ++p) {
+        const int64_t row = cbase + order[p];
+        float x[NREG][VW];
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          const int d0 = (r * GROUP + gl) * VW;
+          if constexpr (VW == 4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d0 < D) t = load4<KIND>(a.X, row, a.ld, d0);
+            x[r][0] = t.x; x[r][1] = t.y; x[r][2] = t.z; x[r][3] = t.w;
+          } else {
+            x[r][0] = d0 < D ? load1<KIND>(a.X, row, a.ld, d0) : 0.f;
+          }
+        }
+        if constexpr (DescTraits<KIND>::rootsift) {
+          float sm = 0.f;
+#pragma unroll
+          for (int r = 0; r < NREG; ++r)
+#pragma unroll
+            for (int q = 0; q < VW; ++q) sm += x[r][q];
+          sm = wave_sum_xor(sm, GROUP);
+#pragma unroll
+          for (int r = 0; r < NREG; ++r)
+#pragma unroll
+            for (int q = 0; q < VW; ++q) x[r][q] = rootsift_apply(x[r][q], sm);
+        }
+#pragma unroll
+        for (int r = 0; r < NREG; ++r)
+#pragma unroll
+          for (int q = 0; q < VW; ++q) acc[r][q] += (x[r][q] - c[r][q]);
+      }
+
+      if (!last) {
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          const int d0 = (r * GROUP + gl) * VW;
+#pragma unroll
+          for (int q = 0; q < VW; ++q)
+            if (d0 + q < D) out_img[(int64_t)k * D + d0 + q] = acc[r][q];
+        }
+        continue;
+      }
+
+      // ---- K3: power norm, per-cluster norm + eps, divide
+      float part = 0.f;
+#pragma unroll
+      for (int r = 0; r < NREG; ++r)
+#pragma unroll
+        for (int q = 0; q < VW; ++q) {
+          const int d = (r * GROUP + gl) * VW + q;
+          acc[r][q] = d < D ? power_norm(acc[r][q], a.power) : 0.f;
+          const float t = norm_accum(acc[r][q], a.norm_mode, a.norm_p);
+          part = a.norm_mode == 3 ? fmaxf(part, t) : part + t;
+        }
+      float nrm = a.norm_mode == 3 ? wave_max_xor(part, GROUP) : wave_sum_xor(part, GROUP);
+      if (a.norm_mode == 2) nrm = sqrtf(nrm);
+      else if (a.norm_mode == 0) nrm = powf(nrm, 1.f / a.norm_p);
+      const float den = nrm + a.eps;
+      float sq = 0.f;
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) {
+        const int d0 = (r * GROUP + gl) * VW;
+        float o[VW];
+#pragma unroll
+        for (int q = 0; q < VW; ++q) {
+          o[q] = acc[r][q] / den;
+          if (d0 + q < D) sq += o[q] * o[q];
+        }
+        if constexpr (VW == 4) {
+          if (d0 < D) *reinterpret_cast<float4*>(out_img + (int64_t)k * D + d0) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          if (d0 < D) out_img[(int64_t)k * D + d0] = o[0];
+        }
+      }
+      sq = wave_sum_xor(sq, GROUP);
+      if (gl == 0) rowsq[k] = sq;
+    }
+    __syncthreads();
+  }
+
+  // ---- global 1/||row||_2 for the cosine step (sklearn normalize: zero norm -> 1), fixed order
+  if (a.inv_norm != nullptr && wave == 0) {
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += rowsq[k];
+    s = wave_sum_xor(s, 64);
+    if (lane == 0) a.inv_norm[img] = s > 0.f ? 1.f / sqrtf(s) : 1.f;
+  }
+}
+
+template <int KIND, int GROUP, int VW, int NREG>
+static int launch_agg_inst(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, size_t lds) {
+  auto k = vlad_aggregate_kernel<KIND, GROUP, VW, NREG>;
+  PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds));
+  hipLaunchKernelGGL(k, dim3((unsigned)n_images), dim3(AGG_THREADS), lds, ctx->stream, a);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+template <int KIND>
+static int launch_agg_kind(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, size_t lds, bool vec) {
+  const int D = a.D;
+  if (vec) {  // 32 lanes x float4 = 128 dims per register step
+    const int nreg = (D + 127) / 128;
+    if (nreg <= 1) return launch_agg_inst<KIND, 32, 4, 1>(ctx, a, n_images, lds);
+    if (nreg <= 2) return launch_agg_inst<KIND, 32, 4, 2>(ctx, a, n_images, lds);
+    if (nreg <= 4) return launch_agg_inst<KIND, 32, 4, 4>(ctx, a, n_images, lds);
+    if (nreg <= 8) return launch_agg_inst<KIND, 32, 4, 8>(ctx, a, n_images, lds);
+  } else {    // 64 lanes x 1 float
+    const int nreg = (D + 63) / 64;
+    if (nreg <= 2) return launch_agg_inst<KIND, 64, 1, 2>(ctx, a, n_images, lds);
+    if (nreg <= 4) return launch_agg_inst<KIND, 64, 1, 4>(ctx, a, n_images, lds);
+    if (nreg <= 8) return launch_agg_inst<KIND, 64, 1, 8>(ctx, a, n_images, lds);
+    if (nreg <= 16) return launch_agg_inst<KIND, 64, 1, 16>(ctx, a, n_images, lds);
+  }
+  PVS_FAIL(PVS_ERR_UNSUPPORTED, "descriptor dimension %d too large for the VLAD aggregate kernel (max 1024)", D);
+}
+
+int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int ld,
+                          const int64_t* d_offsets, int64_t n_images, const int32_t* d_labels,
+                          const pvs_norm_params& prm, float* d_out, float* d_inv_norm) {
+  if (n_images <= 0) return PVS_OK;
+  if (cb->K > 2048) PVS_FAIL(PVS_ERR_UNSUPPORTED, "K = %d exceeds the VLAD aggregate kernel limit (2048)", cb->K);
+  if (n_images > 0x7fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "too many images in one call");
+  AggArgs a{};
+  a.X = d_desc; a.D = cb->D; a.ld = ld; a.offsets = d_offsets; a.labels = d_labels; a.cent = cb->d_cent;
+  a.K = cb->K; a.power = (float)prm.power_norm_weight; a.eps = (float)prm.epsilon;
+  const double ord = prm.norm_order;
+  if (std::isnan(ord) || ord <= 0.0) PVS_FAIL(PVS_ERR_UNSUPPORTED, "norm_order must be > 0 or +inf (got %g)", ord);
+  a.norm_mode = std::isinf(ord) ? 3 : (ord == 2.0 ? 2 : (ord == 1.0 ? 1 : 0));
+  a.norm_p = (float)ord;
+  a.out = d_out; a.inv_norm = d_inv_norm;
+  const int esz = kind == PVS_DESC_U8_ROOTSIFT ? 1 : 4;
+  const bool vec = (cb->D % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_desc) % (4 * esz)) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(d_out) % 16) == 0);
+  const size_t lds = (size_t)(AGG_WAVES * cb->K + cb->K + 1) * 4 + (size_t)cb->K * 4 + (size_t)AGG_WAVES * 4 + (size_t)AGG_CHUNK * 2 + 16;
+  ScopedTimer tm(ctx, T_AGGREGATE);
+  switch (kind) {
+    case PVS_DESC_F32: return launch_agg_kind<PVS_DESC_F32>(ctx, a, n_images, lds, vec);
+    case PVS_DESC_F32_ROOTSIFT: return launch_agg_kind<PVS_DESC_F32_ROOTSIFT>(ctx, a, n_images, lds, vec);
+    case PVS_DESC_U8_ROOTSIFT: return launch_agg_kind<PVS_DESC_U8_ROOTSIFT>(ctx, a, n_images, lds, vec);
+    default: PVS_FAIL(PVS_ERR_INVALID, "unknown descriptor kind %d", kind);
+  }
+}
+
+}  // namespace pvs

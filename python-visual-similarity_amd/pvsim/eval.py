@@ -1,0 +1,92 @@
+"""Retrieval metrics with the signatures of pyvisim/eval.py:13-145, batched on the MI355X.
+
+The reference loops over queries in Python: encode one query, cosine against the whole database (which
+sklearn re-normalises every time), full argsort, slice k.  Here all queries are encoded together, scored
+with ONE Q x N similarity GEMM and ranked with the fused top-k kernel; the label bookkeeping is unchanged.
+Ranking order is (score descending, index ascending) -- identical to the reference's lists wherever its
+own (non-stable) argsort is unambiguous, i.e. on tie-free scores."""
+from __future__ import annotations
+
+from typing import Iterable
+
+import numpy as np
+
+from ._utils import cosine_similarity  # re-exported like the reference's `from ._utils import *`
+from .engine import default_context
+
+__all__ = ["retrieve_top_k_similar", "top_k_map", "top_k_accuracy"]
+
+_K_DEVICE_MAX = 1024
+
+
+def _first_rows(encoder, queries) -> np.ndarray:
+    """encoder.encode(query) per query, keeping row 0 (the reference scores `cosine(...)[0]`), stacked."""
+    queries = list(queries)
+    if queries and all(isinstance(q, np.ndarray) and q.ndim == 3 for q in queries):
+        enc = encoder.encode(queries)                       # one batched encode
+        return enc.reshape(len(queries), -1) if enc.ndim == 1 else enc
+    rows = []
+    for q in queries:
+        v = encoder.encode(q)
+        rows.append(v.reshape(1, -1)[0] if v.ndim == 1 else v[0])
+    return np.vstack(rows) if rows else np.zeros((0, 0), np.float32)
+
+
+def _rank(query_vecs: np.ndarray, all_vectors: np.ndarray, k: int | None, ctx=None):
+    """-> (indices (nq, k') int64, scores (nq, k')) with k' = min(k, N) (k=None: all N)."""
+    ctx = ctx or default_context()
+    n = all_vectors.shape[0]
+    kk = n if k is None else max(0, min(int(k), n))
+    if query_vecs.shape[0] == 0 or kk == 0:
+        return np.zeros((query_vecs.shape[0], 0), np.int64), np.zeros((query_vecs.shape[0], 0), np.float32)
+    if query_vecs.shape[-1] <= 1 or all_vectors.shape[-1] <= 1:
+        raise ValueError(f"Cosine similarity requires at least 2 features. Got {query_vecs.shape[-1]} features "
+                         f"for x and {all_vectors.shape[-1]} features for y.")
+    if kk > _K_DEVICE_MAX:
+        raise NotImplementedError(f"ranking depth {kk} exceeds the device top-k limit ({_K_DEVICE_MAX})")
+    q32 = np.ascontiguousarray(query_vecs, dtype=np.float32)
+    d32 = np.ascontiguousarray(all_vectors, dtype=np.float32)
+    return ctx.cosine_topk(q32, d32, kk)
+
+
+def retrieve_top_k_similar(uploaded_image: np.ndarray, dataset: dict[str, np.ndarray], encoder,
+                           k: int = 5) -> list[tuple[str, float]]:
+    """[(image_path, similarity)] of the k most similar database entries, best first."""
+    all_vectors, all_paths = np.array(list(dataset.values())), list(dataset.keys())
+    query_vector = encoder.encode(uploaded_image)
+    if query_vector.ndim == 1:
+        query_vector = query_vector.reshape(1, -1)
+    idx, val = _rank(query_vector[:1], all_vectors, k, getattr(encoder, "context", None))
+    return [(all_paths[i], s) for i, s in zip(idx[0], val[0])]
+
+
+def top_k_map(images: Iterable[np.ndarray], image_labels: Iterable[int], encoding_map: dict[str, np.ndarray],
+              path_labels_dict: dict[str, int], encoder, k: int = None) -> float:
+    """Mean average precision; R is counted inside the (possibly truncated) ranked list (eval.py:95)."""
+    all_vectors, all_paths = np.array(list(encoding_map.values())), list(encoding_map.keys())
+    labels = list(image_labels)
+    q = _first_rows(encoder, images)
+    idx, _ = _rank(q, all_vectors, k, getattr(encoder, "context", None))
+    db_labels = [path_labels_dict[p] for p in all_paths]
+    aps = []
+    for row, true_label in zip(idx, labels):
+        relevant_count, precision_sum = 0, 0.0
+        for rank, i in enumerate(row, start=1):
+            if db_labels[i] == true_label:
+                relevant_count += 1
+                precision_sum += relevant_count / rank
+        aps.append(precision_sum / relevant_count if relevant_count > 0 else 0.0)
+    return float(np.mean(aps))
+
+
+def top_k_accuracy(images: Iterable[np.ndarray], image_labels: Iterable[int], encoding_map: dict[str, np.ndarray],
+                   path_labels_dict: dict[str, int], encoder, k: int) -> float:
+    """Fraction of queries with at least one same-label entry among their k nearest (eval.py:102-145)."""
+    all_paths, all_vectors = list(encoding_map.keys()), np.array(list(encoding_map.values()))
+    images = list(images)
+    labels = list(image_labels)
+    q = _first_rows(encoder, images)
+    idx, _ = _rank(q, all_vectors, k, getattr(encoder, "context", None))
+    db_labels = [path_labels_dict[p] for p in all_paths]
+    correct = sum(1 for row, true_label in zip(idx, labels) if any(db_labels[i] == true_label for i in row))
+    return float(correct / len(images))

@@ -1,0 +1,304 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (pvsim.Context is the ctypes binding of
+include/pvsim.h), against the golden vectors of the reference and against the CPU oracle on seeded inputs.
+
+Tolerances (also in DESIGN.md):
+  labels / top-k indices   bit-exact (near-tie descriptors excepted, see test_labels_large_only_near_ties)
+  VLAD values (fp32)       5e-7 abs   (sums are in reference order; only the norm reduction order differs)
+  Fisher values (fp64)     1e-9 abs   (device computes in fp64; reduction order differs from NumPy's BLAS)
+  cosine (fp32)            2e-6 abs   (fp32 GEMM summation order; L up to 65792)
+"""
+import numpy as np
+import pytest
+
+import pvsim_oracle as orc
+from conftest import load_golden
+from pvsim import synth, pack_descriptors
+from pvsim.engine import DESC_F32, DESC_F32_ROOTSIFT, DESC_U8_ROOTSIFT
+
+pytestmark = pytest.mark.gpu
+
+VLAD_ATOL = 5e-7
+FISHER_ATOL = 1e-9
+COS_ATOL = 2e-6
+
+
+def _raws(g, key_raw="raw_u8", key_off="offsets"):
+    return orc.split_ragged(g[key_raw], g[key_off])
+
+
+# ======================================================================================= VLAD
+@pytest.mark.parametrize("kind", [DESC_U8_ROOTSIFT, DESC_F32_ROOTSIFT, DESC_F32])
+def test_vlad_golden_k256(gpu_ctx, tables, kind):
+    g = load_golden("vlad_k256_d128")
+    cb = gpu_ctx.codebook(tables["centroids"])
+    if kind == DESC_U8_ROOTSIFT:
+        packed = g["raw_u8"]
+    elif kind == DESC_F32_ROOTSIFT:
+        packed = g["raw_u8"].astype(np.float32)
+    else:
+        packed = synth.rootsift(g["raw_u8"].astype(np.float32))
+    v, labels = gpu_ctx.vlad_encode(cb, packed, g["offsets"], kind, return_labels=True)
+    assert np.array_equal(labels, g["labels"])
+    assert v.shape == g["vlad"].shape and v.dtype == np.float32
+    np.testing.assert_allclose(v, g["vlad"], rtol=0, atol=VLAD_ATOL)
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("default", {}), ("p05", {"power": 0.5}), ("l1", {"norm_order": 1}),
+    ("p03_l1", {"power": 0.3, "norm_order": 1}), ("eps", {"epsilon": 1e-3})])
+def test_vlad_small_variants(gpu_ctx, tag, kw):
+    g = load_golden("small_k16_d8")
+    cb = gpu_ctx.codebook(g["centroids"])
+    x = (g["raw"] / np.float32(16.0)).astype(np.float32)
+    v, labels = gpu_ctx.vlad_encode(cb, x, g["offsets"], DESC_F32, return_labels=True, **kw)
+    assert np.array_equal(labels, g["labels"])          # incl. the duplicated-centroid first-min tie
+    np.testing.assert_allclose(v, g["vlad_" + tag], rtol=0, atol=2e-6 if "p03" in tag else VLAD_ATOL)
+
+
+def test_vlad_pca_golden(gpu_ctx, tables):
+    g = load_golden("vlad_k256_d128")
+    gp = load_golden("vlad_pca64_k256")
+    n = int(gp["n_images"])
+    cb = gpu_ctx.codebook(tables["centroids_pca64"])
+    pca = gpu_ctx.pca(tables["pca_components"], tables["pca_mean"])
+    off = g["offsets"][: n + 1]
+    v = gpu_ctx.vlad_encode(cb, g["raw_u8"][: off[-1]], off, DESC_U8_ROOTSIFT, pca=pca)
+    np.testing.assert_allclose(v, gp["vlad"], rtol=0, atol=5e-6)     # fp32 PCA GEMM order (see oracle test)
+
+
+@pytest.mark.parametrize("K,D", [(256, 128), (40, 100), (300, 64), (64, 30), (32, 200), (256, 514)])
+def test_vlad_shapes_vs_oracle(gpu_ctx, K, D):
+    """Ragged images incl. empty, single-descriptor and > 4096-descriptor (chunk continuation) ones; K / D
+    that exercise cluster padding (K=40), two cluster blocks (K=300), scalar loads (D=30), two dim slabs
+    (D=200, 514)."""
+    rng = np.random.default_rng(K * 1000 + D)
+    C = rng.normal(size=(K, D)).astype(np.float32)
+    counts = [0, 1, 5, 33, 257, 1000, 4500 if D <= 128 else 300, 64]
+    imgs = [(C[rng.integers(0, K, n)] + 0.7 * rng.normal(size=(n, D))).astype(np.float32) for n in counts]
+    packed, offsets = pack_descriptors(imgs, D)
+    cb = gpu_ctx.codebook(C)
+    v, labels = gpu_ctx.vlad_encode(cb, packed, offsets, DESC_F32, return_labels=True)
+    ref_labels = orc.kmeans_predict(packed, C)
+    lab64, gap = orc.assignment_margin(packed, C)
+    bad = labels != ref_labels
+    assert np.all(gap[bad] < 1e-4 * (1 + np.abs(packed[bad]).sum(1)))   # only near-ties may differ
+    ref = np.vstack([orc.vlad_normalise(orc.vlad_aggregate(x, labels[o:o + len(x)], C), 1, 2, 1e-9).reshape(-1)
+                     if len(x) else np.zeros(K * D, np.float32)
+                     for x, o in zip(imgs, offsets[:-1])])
+    np.testing.assert_allclose(v, ref, rtol=0, atol=2e-6)
+    assert not v[0].any()                                               # empty image -> zero row
+
+
+def test_labels_large_only_near_ties(gpu_ctx, tables):
+    """200k RootSIFT descriptors: labels equal the fp32 oracle's except where the exact fp64 margin
+    between the two best centroids is below fp32 resolution (any fp32 evaluation may differ there)."""
+    rng = np.random.default_rng(2024)
+    raw = synth.sift_like(200_000, rng)
+    x = synth.rootsift(raw)
+    C = tables["centroids"]
+    cb = gpu_ctx.codebook(C)
+    _, labels = gpu_ctx.vlad_encode(cb, raw.astype(np.uint8), np.array([0, len(raw)], np.int64), DESC_U8_ROOTSIFT,
+                                    return_labels=True)
+    ref = orc.kmeans_predict(x, C)
+    lab64, gap = orc.assignment_margin(x, C)
+    bad = labels != ref
+    print(f"label mismatches vs fp32 oracle: {bad.sum()} / {len(ref)}; vs exact fp64: {(labels != lab64).sum()}")
+    assert bad.sum() <= 20 and np.all(gap[bad] < 5e-6)
+    assert np.all(gap[labels != lab64] < 5e-6)
+
+
+def test_vlad_bitwise_reproducible(gpu_ctx, tables):
+    rng = np.random.default_rng(5)
+    raws = [synth.sift_like(int(n), rng).astype(np.uint8) for n in rng.integers(1, 900, 64)]
+    packed, offsets = pack_descriptors(raws, 128, np.uint8)
+    cb = gpu_ctx.codebook(tables["centroids"])
+    a = gpu_ctx.vlad_encode(cb, packed, offsets, DESC_U8_ROOTSIFT)
+    b = gpu_ctx.vlad_encode(cb, packed, offsets, DESC_U8_ROOTSIFT)
+    assert np.array_equal(a, b)                                          # no float atomics anywhere
+    rows = a.reshape(64, 256, 128)
+    nrm = np.linalg.norm(rows, axis=2)
+    assert np.all((np.abs(nrm - 1) < 1e-5) | (nrm == 0))                 # intra-normalisation property
+
+
+# ======================================================================================= Fisher
+def test_fisher_golden_k256(gpu_ctx, tables):
+    g = load_golden("vlad_k256_d128")
+    f = load_golden("fisher_k256_d128")
+    raws = _raws(g)
+    sel = [raws[i] for i in f["image_index"]]
+    gm = gpu_ctx.gmm(tables["gmm_weights"], tables["gmm_means"], tables["gmm_covariances"])
+    packed, offsets = pack_descriptors(sel, 128, np.uint8)
+    out = gpu_ctx.fisher_encode(gm, packed, offsets, DESC_U8_ROOTSIFT)
+    assert out.dtype == np.float64 and out.shape == f["fisher"].shape
+    np.testing.assert_allclose(out, f["fisher"], rtol=0, atol=FISHER_ATOL)
+
+
+@pytest.mark.parametrize("tag,kw", [("default", {}), ("p1", {"power": 1.0}), ("l1", {"norm_order": 1}),
+                                    ("p03", {"power": 0.3})])
+def test_fisher_small_variants(gpu_ctx, tag, kw):
+    g = load_golden("small_k16_d8")
+    gm = gpu_ctx.gmm(g["gmm_weights"], g["gmm_means"], g["gmm_covariances"])
+    x = (g["raw"] / np.float32(16.0)).astype(np.float32)
+    out = gpu_ctx.fisher_encode(gm, x, g["offsets"], DESC_F32, **kw)
+    np.testing.assert_allclose(out, g["fisher_" + tag], rtol=0, atol=FISHER_ATOL)
+
+
+def test_fisher_deep_like_and_pca(gpu_ctx, tables):
+    f = load_golden("fisher_deep_k32_d96")
+    gm = gpu_ctx.gmm(f["gmm_weights"], f["gmm_means"], f["gmm_covariances"])
+    packed, offsets = pack_descriptors(list(f["desc"]), 96)
+    np.testing.assert_allclose(gpu_ctx.fisher_encode(gm, packed, offsets), f["fisher"], rtol=0, atol=FISHER_ATOL)
+    g = load_golden("vlad_k256_d128")
+    fp = load_golden("fisher_pca64_k64")
+    n = int(fp["n_images"])
+    gmp = gpu_ctx.gmm(tables["gmmp_weights"], tables["gmmp_means"], tables["gmmp_covariances"])
+    pca = gpu_ctx.pca(tables["pca_components"], tables["pca_mean"])
+    off = g["offsets"][: n + 1]
+    out = gpu_ctx.fisher_encode(gmp, g["raw_u8"][: off[-1]], off, DESC_U8_ROOTSIFT, pca=pca)
+    np.testing.assert_allclose(out, fp["fisher"], rtol=0, atol=2e-6)       # fp32 PCA GEMM order
+
+
+# ======================================================================================= cosine
+def test_cosine_golden(gpu_ctx):
+    g = load_golden("cosine")
+    c32 = gpu_ctx.cosine(g["a32"], g["b32"])
+    assert c32.dtype == np.float32
+    np.testing.assert_allclose(c32, g["cos32"], rtol=0, atol=COS_ATOL)
+    assert not c32[:, 2].any() and np.array_equal(c32[:, 7], c32[:, 4])
+    c64 = gpu_ctx.cosine(g["a32"].astype(np.float64) * 1.7, g["b32"].astype(np.float64))
+    assert c64.dtype == np.float64
+    np.testing.assert_allclose(c64, g["cos64"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(gpu_ctx.cosine(g["a32"], g["b32"].astype(np.float64)), g["cos_mixed"], atol=1e-12)
+    v = load_golden("vlad_k256_d128")["vlad"]
+    np.testing.assert_allclose(gpu_ctx.cosine(v, v), g["vlad_self"], rtol=0, atol=COS_ATOL)
+
+
+@pytest.mark.parametrize("M,N,L", [(1, 1, 2), (3, 200, 40), (130, 257, 32768), (129, 128, 100), (64, 70, 37),
+                                   (300, 5, 65792)])
+def test_cosine_shapes_vs_oracle(gpu_ctx, M, N, L):
+    rng = np.random.default_rng(M * 7 + N * 3 + L)
+    a = rng.normal(size=(M, L)).astype(np.float32)
+    b = rng.normal(size=(N, L)).astype(np.float32)
+    if N > 2:
+        b[1] = 0.0
+    np.testing.assert_allclose(gpu_ctx.cosine(a, b), orc.cosine_similarity(a, b), rtol=0, atol=COS_ATOL)
+
+
+# ======================================================================================= top-k
+def _check_topk(gpu_ctx, q, db, k):
+    idx, val = gpu_ctx.cosine_topk(q, db, k)
+    s = gpu_ctx.cosine(q, db)                        # rank the device's own scores: isolates the select kernel
+    ridx, rval = orc.topk(s, k)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(val, rval)
+
+
+@pytest.mark.parametrize("nq,N,k", [(5, 10, 3), (7, 8189, 5), (3, 8189, 100), (2, 20000, 1000), (4, 300, 300),
+                                    (2, 40000, 17)])
+def test_topk_vs_stable_argsort(gpu_ctx, nq, N, k):
+    rng = np.random.default_rng(nq * N + k)
+    L = 64
+    db = rng.normal(size=(N, L)).astype(np.float32)
+    db[N // 2] = db[N // 3]                          # a duplicate row -> exact score tie, index order decides
+    db[N - 1] = 0.0                                  # a zero row
+    q = rng.normal(size=(nq, L)).astype(np.float32)
+    _check_topk(gpu_ctx, q, db, k)
+
+
+def test_topk_all_ties_and_self(gpu_ctx):
+    db = np.ones((500, 16), np.float32)              # every score identical: pure index order
+    idx, _ = gpu_ctx.cosine_topk(db[:3], db, 9)
+    assert np.array_equal(idx, np.tile(np.arange(9), (3, 1)))
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(1000, 256)).astype(np.float32)
+    idx, val = gpu_ctx.cosine_topk(x, x, 1)          # self retrieval: top-1 is the row itself
+    assert np.array_equal(idx[:, 0], np.arange(1000)) and np.all(np.abs(val - 1) < 1e-5)
+
+
+def test_retrieval_golden_topk_lists(gpu_ctx, tables):
+    g = load_golden("eval_db64")
+    cb = gpu_ctx.codebook(tables["centroids"])
+    dbv = gpu_ctx.vlad_encode(cb, g["db_raw_u8"], g["db_offsets"], DESC_U8_ROOTSIFT)
+    qv = gpu_ctx.vlad_encode(cb, g["q_raw_u8"], g["q_offsets"], DESC_U8_ROOTSIFT)
+    np.testing.assert_allclose(gpu_ctx.cosine(qv, dbv), g["sims"], rtol=0, atol=COS_ATOL)
+    idx, val = gpu_ctx.cosine_topk(qv, dbv, 7)
+    assert np.array_equal(idx, g["top7_index"])       # bit-identical to the reference's lists
+    np.testing.assert_allclose(val, g["top7_score"], rtol=0, atol=COS_ATOL)
+
+
+# ======================================================================================= drop-in API
+def _encoders(tables):
+    from pvsim.encoders import VLADEncoder, FisherVectorEncoder
+    from pvsim.features import Lambda
+    from pvsim.models import KMeansModel, GMMModel
+    fx = Lambda(synth.rootsift, 128)
+    v = VLADEncoder(fx, kmeans_model=KMeansModel(tables["centroids"]))
+    f = FisherVectorEncoder(fx, gmm_model=GMMModel(tables["gmm_weights"], tables["gmm_means"], tables["gmm_covariances"]))
+    return v, f
+
+
+def test_api_encode_similarity_pipeline(tables):
+    from pvsim.encoders import Pipeline
+    g = load_golden("vlad_k256_d128")
+    raws = [r.astype(np.float32) for r in _raws(g)]
+    venc, fenc = _encoders(tables)
+    np.testing.assert_allclose(venc.encode(raws), g["vlad"], rtol=0, atol=VLAD_ATOL)
+    c = load_golden("cosine")
+    s = venc.similarity_score(raws[:3], raws[2:7])
+    assert s.dtype == np.float32 and s.shape == (3, 5)
+    np.testing.assert_allclose(s, c["similarity_score_3x5"], rtol=0, atol=COS_ATOL)
+    p = load_golden("pipeline")
+    pipe = Pipeline([venc, fenc])
+    enc = pipe.encode(raws[1:4])
+    assert enc.shape == p["encoded"].shape
+    np.testing.assert_allclose(enc, p["encoded"], rtol=0, atol=VLAD_ATOL)
+    np.testing.assert_allclose(pipe.similarity_score(raws[1:3], raws[2:4]), p["score"], rtol=0, atol=COS_ATOL)
+    # descriptor-level entry with fused RootSIFT from uint8 gives the same encodings
+    np.testing.assert_allclose(venc.encode_descriptors(_raws(g), rootsift=True), g["vlad"], rtol=0, atol=VLAD_ATOL)
+    # flatten=False stacks (K, D) blocks (vlad.py:110-115)
+    venc.flatten = False
+    assert venc.encode(raws[:2]).shape == (2 * 256, 128)
+
+
+def test_api_eval_functions(tables):
+    from pvsim import eval as ev
+    g = load_golden("eval_db64")
+    venc, _ = _encoders(tables)
+    db = [r.astype(np.float32) for r in _raws(g, "db_raw_u8", "db_offsets")]
+    qs = [r.astype(np.float32) for r in _raws(g, "q_raw_u8", "q_offsets")]
+    paths = [f"img_{i:03d}.jpg" for i in range(len(db))]
+    emap = dict(zip(paths, venc.encode(db)))
+    plab = dict(zip(paths, [int(l) for l in g["db_labels"]]))
+    top = ev.retrieve_top_k_similar([qs[0]], emap, venc, k=7)
+    assert [paths.index(p) for p, _ in top] == list(g["top7_index"][0])
+    np.testing.assert_allclose([s for _, s in top], g["top7_score"][0], atol=COS_ATOL)
+    wrapped = [[q] for q in qs]
+    labels = list(g["q_labels"])
+    assert ev.top_k_accuracy(wrapped, labels, emap, plab, venc, 1) == float(g["acc_k1"])
+    assert ev.top_k_accuracy(wrapped, labels, emap, plab, venc, 5) == float(g["acc_k5"])
+    assert abs(ev.top_k_map(wrapped, labels, emap, plab, venc, 5) - float(g["map_k5"])) < 1e-12
+    assert abs(ev.top_k_map(wrapped, labels, emap, plab, venc, 10) - float(g["map_k10"])) < 1e-12
+    assert abs(ev.top_k_map(wrapped, labels, emap, plab, venc, None) - float(g["map_all"])) < 1e-12
+
+
+# ======================================================================================= full-size properties
+def test_config2_sized_properties(gpu_ctx, tables):
+    """2048 ragged images (config-2 generator): oracle parity on a subsample, size-independent properties on
+    all of it (unit / zero cluster rows, self-retrieval, symmetric scores, idempotent encode)."""
+    rng = np.random.default_rng(1235)
+    counts = synth.ragged_counts(2048, 1235)
+    raws = [synth.sift_like(int(n), rng).astype(np.uint8) for n in counts]
+    packed, offsets = pack_descriptors(raws, 128, np.uint8)
+    cb = gpu_ctx.codebook(tables["centroids"])
+    v = gpu_ctx.vlad_encode(cb, packed, offsets, DESC_U8_ROOTSIFT)
+    sub = rng.choice(2048, 24, replace=False)
+    ref = orc.vlad_encode([synth.rootsift(raws[i]) for i in sub], tables["centroids"])
+    np.testing.assert_allclose(v[sub], ref, rtol=0, atol=VLAD_ATOL)
+    nrm = np.linalg.norm(v.reshape(2048, 256, 128), axis=2)
+    assert np.all((np.abs(nrm - 1) < 1e-5) | (nrm == 0))
+    idx, val = gpu_ctx.cosine_topk(v, v, 5)
+    assert np.array_equal(idx[:, 0], np.arange(2048)) and np.all(np.abs(val[:, 0] - 1) < 1e-5)
+    s = gpu_ctx.cosine(v[:300], v[:300])
+    assert np.abs(s - s.T).max() < 1e-6
+    ridx, _ = orc.topk(orc.cosine_similarity(v[sub], v), 5)
+    assert np.array_equal(idx[sub], ridx)

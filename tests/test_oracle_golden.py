@@ -192,3 +192,30 @@ def test_near_tie_labels_are_only_near_ties(tables):
     lab64, gap = orc.assignment_margin(x, C)
     bad = lab32 != lab64
     assert bad.sum() <= 5 and np.all(gap[bad] < 2e-6)
+
+
+# ----------------------------------------------------------------------------- the C restatement
+def test_c_oracle_vlad_matches_golden(tables):
+    import pvsim_oracle_c as orc_c
+    g = load_golden("vlad_k256_d128")
+    for threads in (1, 0):
+        V, labels = orc_c.vlad_encode(g["raw_u8"], g["offsets"], tables["centroids"], threads=threads,
+                                      return_labels=True)
+        assert np.array_equal(labels, g["labels"])
+        np.testing.assert_allclose(V, g["vlad"], rtol=0, atol=VLAD_ATOL)
+
+
+def test_c_oracle_variants_and_retrieval(tables):
+    import pvsim_oracle_c as orc_c
+    s = load_golden("small_k16_d8")
+    x = (s["raw"] / np.float32(16.0)).astype(np.float32)
+    for tag, kw in (("default", {}), ("p05", {"power": 0.5}), ("l1", {"norm_order": 1.0}),
+                    ("p03_l1", {"power": 0.3, "norm_order": 1.0}), ("eps", {"eps": 1e-3})):
+        V = orc_c.vlad_encode(x, s["offsets"], s["centroids"], **kw)
+        np.testing.assert_allclose(V, s["vlad_" + tag], rtol=0, atol=5e-7)
+    g = load_golden("eval_db64")
+    dbv = orc_c.vlad_encode(g["db_raw_u8"], g["db_offsets"], tables["centroids"])
+    qv = orc_c.vlad_encode(g["q_raw_u8"], g["q_offsets"], tables["centroids"])
+    idx, val = orc_c.retrieve(qv, dbv, 7)
+    assert np.array_equal(idx, g["top7_index"])
+    np.testing.assert_allclose(val, g["top7_score"], atol=5e-7)
