@@ -52,6 +52,7 @@ int launch_row_inv_norms(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L
 // ------------------------------------------------------------------------------------- K6 fp32 MFMA
 constexpr int GT_M = 128, GT_N = 128, GT_K = 32;
 constexpr int GEMM_THREADS = 256;
+constexpr int GEMM_KBLOCK = 1024;  // k-values per MFMA accumulation chain (see kernel)
 constexpr int TILE_BYTES = GT_M * GT_K * 4;  // 16 KiB per operand per stage
 
 struct GemmArgs {
@@ -109,13 +110,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void cosine_gemm_f32_kernel(GemmAr
   const int tm = first_m + rem % gsz, tn = rem / gsz;
   const int64_t m0 = (int64_t)tm * GT_M, n0 = (int64_t)tn * GT_N;
 
-  f32x16 acc[2][2];
+  // Two-level summation: the MFMA chain (a k-ordered fp32 fma chain) runs over at most GEMM_KBLOCK k-values,
+  // then its tile is added into `tot`.  A single 32768-long chain drifts ~4e-6 relative (random-walk
+  // rounding); blocked at 1024 the error is ~1.6e-7, the level of a blocked BLAS sgemm (the reference).
+  f32x16 acc[2][2], tot[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; tot[a][b][r] = 0.f; }
 
   const int nk = (int)((g.L + GT_K - 1) / GT_K);
   stage_tile(g.A, g.M, g.L, m0, 0, smem, wave, lane);
@@ -147,9 +151,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void cosine_gemm_f32_kernel(GemmAr
       PVS_MF(a0, b0, acc[0][0]) PVS_MF(a0, b1, acc[0][1]) PVS_MF(a1, b0, acc[1][0]) PVS_MF(a1, b1, acc[1][1])
 #undef PVS_MF
     }
+    if ((kt & (GEMM_KBLOCK / GT_K - 1)) == GEMM_KBLOCK / GT_K - 1) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          tot[a][b] += acc[a][b];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] += tot[a][b];
 
   // ---- epilogue: scale by 1/(||a|| ||b||); C/D layout col = lane&31, row = (reg&3)+8*(reg>>2)+4*h
 #pragma unroll
