@@ -30,6 +30,23 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-l
 K_CLUSTERS, DIM, TOPK = 256, 128, 5
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM-side bytes per launch of a kernel from the newest committed PMC summary (profiles/rNN_pmc_hbm.json,
+    produced by profiles/summarize.py from separate rocprofv3 --pmc passes of this same command)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm.json")))
+    if not files:
+        return None, None
+    try:
+        data = json.load(open(files[-1]))
+        for name, d in data["kernels"].items():
+            if name.startswith(kernel_prefix) and "hbm_bytes_per_launch_corrected" in d:
+                return d["hbm_bytes_per_launch_corrected"], os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +197,9 @@ def main():
     flop_per_launch = 2.0 * n_loc * (min(per, N)) * L      # one launch = local queries x one rank block
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flop_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
+    traffic, traffic_src = pmc_traffic("pvs::cosine_gemm")
+    if world != 1 or N != 8189:
+        traffic, traffic_src = None, None             # the committed counters are for the default 1-GPU workload
     stages = {k: {"ms_total": round(v[0], 3), "launches": int(v[1]),
                   "ms_avg": round(v[0] / v[1], 4) if v[1] else None} for k, v in timers.items() if v[1]}
     enc_ms = (timers["assign"][0] + timers["aggregate"][0]) / args.steps
@@ -196,7 +216,7 @@ def main():
                    "K": K_CLUSTERS, "D": DIM, "topk": TOPK, "parallelism": f"image-sharded x{world}"},
         "roofline": {"kernel": "cosine_gemm_f32_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                     "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_ms": round(gemm_avg_ms, 4)},
+                     "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flop_per_launch, "avg_launch_ms": round(gemm_avg_ms, 4)},
         "stages": stages,
         "encode": {"ms_per_step": round(enc_ms, 3), "images_per_s": round(n_loc / (enc_ms * 1e-3), 1) if enc_ms else None,
                    "algorithmic_GBps": round(enc_bytes / (enc_ms * 1e-3) / 1e9, 1) if enc_ms else None,

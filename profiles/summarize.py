@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof/ directory (rocprofv3 CSVs) into the small files committed under profiles/.
+
+    python profiles/summarize.py gpurun_out/prof r01
+
+Expects <dir>/stats (rocprofv3 --kernel-trace --stats), <dir>/fetch (--pmc FETCH_SIZE) and <dir>/write
+(--pmc WRITE_SIZE) -- counters collected in their own passes, as the MI355X guide prescribes."""
+import collections, csv, glob, json, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+
+
+def one(pattern):
+    hits = glob.glob(f"{src}/{pattern}", recursive=True)
+    return hits[0] if hits else None
+
+
+stats = one("stats/**/*_kernel_stats.csv")
+if stats:
+    rows = list(csv.reader(open(stats)))
+    with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        for r in rows:
+            r[0] = r[0][:110]
+            w.writerow(r)
+out = {}
+for name, pattern in (("FETCH_SIZE_KiB", "fetch/**/*_counter_collection.csv"),
+                      ("WRITE_SIZE_KiB", "write/**/*_counter_collection.csv")):
+    path = one(pattern)
+    if not path:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if "pvs::" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        out.setdefault(k, {})[name] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+for k, d in out.items():
+    if "FETCH_SIZE_KiB" in d and "WRITE_SIZE_KiB" in d:
+        f_, w_ = d["FETCH_SIZE_KiB"]["mean_per_launch"], d["WRITE_SIZE_KiB"]["mean_per_launch"]
+        # gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads -> doubled
+        # (MI355X_MICROARCH.md, section HBM); WRITE_SIZE is exact for 16-B-per-lane stores.
+        d["hbm_bytes_per_launch_corrected"] = (2.0 * f_ + w_) * 1024.0
+if out:
+    json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
+                          "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+               "note": "FETCH_SIZE doubled per the gfx950 correction; Infinity-Cache hits are included in these "
+                       "fabric-side counters, so this is traffic beyond L2, an upper bound on HBM bytes",
+               "kernels": out}, open(f"profiles/{tag}_pmc_hbm.json", "w"), indent=1)
+print("wrote", glob.glob(f"profiles/{tag}_*"))

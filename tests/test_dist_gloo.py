@@ -1,0 +1,83 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU host logic: contiguous image sharding, padded all-gather of
+the encoding blocks, per-block ranking with true global indices merged through a running top-k list.
+The GPU scorer is replaced by an oracle-based one (tests may use the oracle); the collective is real (gloo)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _oracle_score_block(q, n_q, db, n_db, inv_q, inv_db, k, col_offset, merge, idx, val):
+    import pvsim_oracle as orc
+    s = orc.cosine_similarity(q[:n_q].numpy(), db[:n_db].numpy())
+    cand_idx = np.tile(np.arange(col_offset, col_offset + n_db), (n_q, 1))
+    cand_val = s
+    if merge:
+        keep = idx[:n_q].numpy() >= 0
+        cand_idx = np.concatenate([np.where(keep, idx[:n_q].numpy(), -1), cand_idx], axis=1)
+        cand_val = np.concatenate([np.where(keep, val[:n_q].numpy(), -np.inf), cand_val], axis=1)
+    order = np.lexsort((cand_idx, -cand_val), axis=1)[:, :k]          # (score desc, index asc)
+    ti = np.take_along_axis(cand_idx, order, 1)
+    tv = np.take_along_axis(cand_val, order, 1).astype(np.float32)
+    kk = ti.shape[1]
+    idx[:n_q, :kk] = torch.from_numpy(ti)
+    val[:n_q, :kk] = torch.from_numpy(tv)
+
+
+def _worker(rank, world, port, n_total, k, out_dir):
+    for p in (os.path.join(REPO, "python-visual-similarity_amd"), os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+        sys.path.insert(0, p)
+    from pvsim import distributed as pd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(123)
+    enc = rng.normal(size=(n_total, 48)).astype(np.float32)           # the whole corpus (same on both ranks)
+    enc[5] = enc[2]                                                   # a tie across/within blocks
+    lo, hi, block = pd.shard_range(n_total, world, rank)
+    enc_loc = torch.zeros((block, 48), dtype=torch.float32)
+    enc_loc[: hi - lo] = torch.from_numpy(enc[lo:hi])
+    inv_loc = torch.ones((block,), dtype=torch.float32)
+    enc_all, inv_all = pd.gather_blocks(enc_loc, inv_loc)
+    assert enc_all.shape == (world * block, 48)
+    idx = torch.full((block, k), -1, dtype=torch.int64)
+    val = torch.full((block, k), float("-inf"), dtype=torch.float32)
+    n_loc = pd.retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, n_total, rank, world, k, _oracle_score_block,
+                                idx, val)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), idx=idx[:n_loc].numpy(), val=val[:n_loc].numpy(), lo=lo, hi=hi,
+             enc=enc)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [11, 16])
+def test_sharded_retrieval_two_ranks_gloo(tmp_path, n_total):
+    import pvsim_oracle as orc
+    from pvsim import distributed as pd
+    world, k = 2, 4
+    port = 29500 + (os.getpid() % 2000) + n_total
+    mp.spawn(_worker, args=(world, port, n_total, k, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    enc = parts[0]["enc"]
+    ridx, rval = orc.topk(orc.cosine_similarity(enc, enc), k)          # single-process answer
+    got_idx = np.concatenate([p["idx"] for p in parts])
+    got_val = np.concatenate([p["val"] for p in parts])
+    assert [int(p["lo"]) for p in parts] == [pd.shard_range(n_total, world, r)[0] for r in range(world)]
+    assert np.array_equal(got_idx, ridx)
+    np.testing.assert_allclose(got_val, rval, atol=1e-6)
+
+
+def test_shard_range_covers_everything():
+    from pvsim.distributed import shard_range
+    for n in (0, 1, 7, 8, 8189, 1_000_000):
+        for w in (1, 2, 4, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(hi - lo <= blk for lo, hi, blk in spans)
