@@ -192,9 +192,19 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (the cosine GEMM): algorithmic flop / measured launch duration
+    # ---- roofline of the dominant kernel (the cosine GEMM): EXECUTED flop / measured launch duration.
+    # One launch = local queries x one rank block.  When the block is the query block itself (self-similarity)
+    # the kernel computes only the upper triangle of 128x128 tiles and mirrors the rest, so the executed flop is
+    # ~half of the algorithmic 2*N*M*L of SURVEY.md section 8(d); `achieved` counts executed flop only (never above peak).
     gemm_ms, gemm_n = timers["cosine_gemm"]
-    flop_per_launch = 2.0 * n_loc * (min(per, N)) * L      # one launch = local queries x one rank block
+    blk = min(per, N)
+    t128 = (n_loc + 127) // 128
+    alg_flop = 2.0 * n_loc * blk * L
+    exec_tiles_sym = t128 * (t128 + 1) // 2
+    exec_flop_sym = 2.0 * 128 * 128 * L * exec_tiles_sym
+    exec_flop_full = 2.0 * 128 * 128 * L * t128 * ((blk + 127) // 128)
+    # per step: one symmetric launch (own block) + (world - 1) full launches
+    flop_per_launch = (exec_flop_sym + (world - 1) * exec_flop_full) / world
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flop_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
     traffic, traffic_src = pmc_traffic("pvs::cosine_gemm")
@@ -216,7 +226,9 @@ def main():
                    "K": K_CLUSTERS, "D": DIM, "topk": TOPK, "parallelism": f"image-sharded x{world}"},
         "roofline": {"kernel": "cosine_gemm_f32_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                     "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flop_per_launch, "avg_launch_ms": round(gemm_avg_ms, 4)},
+                     "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flop_per_launch,
+                     "algorithmic_flop_per_launch": alg_flop,
+                     "algorithmic_equiv_TFLOPs": round(alg_flop / (gemm_avg_ms * 1e-3) / 1e12, 2) if gemm_n else None, "avg_launch_ms": round(gemm_avg_ms, 4)},
         "stages": stages,
         "encode": {"ms_per_step": round(enc_ms, 3), "images_per_s": round(n_loc / (enc_ms * 1e-3), 1) if enc_ms else None,
                    "algorithmic_GBps": round(enc_bytes / (enc_ms * 1e-3) / 1e9, 1) if enc_ms else None,

@@ -1,0 +1,177 @@
+// Variant harness for the exact-fp32 cosine GEMM (not part of libpvsim_hip.so).
+//   hipcc -O3 --offload-arch=gfx950 -o gemm_variants gemm_variants.hip && ./gemm_variants [N] [L]
+// Random normal operands (never zeros: zero operands raise the clock and read high), A == B (self-similarity),
+// every variant checked against fp64 dot products on sampled entries, 1 warm-up + 3 timed launches each.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <vector>
+
+#include "../gemm_f32.hpp"
+
+using namespace pvs;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_normal(float* x, int64_t n, uint64_t seed) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + seed;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+  const float u1 = ((z >> 40) + 1) * (1.0f / 16777217.0f), u2 = ((z >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  // sparse like a VLAD row: ~40 % exact zeros
+  x[i] = (z & 7) < 3 ? 0.f : sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2) * 0.01f;
+}
+
+__global__ void inv_norms(const float* x, int64_t rows, int64_t L, int64_t ld, float* inv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int64_t i = lane; i < L; i += 64) s = fmaf(x[row * ld + i], x[row * ld + i], s);
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  if (lane == 0) inv[row] = s > 0.f ? 1.f / sqrtf(s) : 1.f;
+}
+
+__global__ void ref_samples(const float* x, const float* inv, int64_t L, int64_t ld, const int* sm, const int* sn, int ns, double* out) {
+  const int s = blockIdx.x;
+  if (s >= ns) return;
+  const int lane = threadIdx.x;
+  double acc = 0.0;
+  for (int64_t i = lane; i < L; i += 64) acc += (double)x[(int64_t)sm[s] * ld + i] * (double)x[(int64_t)sn[s] * ld + i];
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if (lane == 0) out[s] = acc * (double)inv[sm[s]] * (double)inv[sn[s]];
+}
+
+__device__ __attribute__((aligned(16))) float d_zero16[4] = {0, 0, 0, 0};
+static int64_t g_ld = 0;  // operand row stride (floats)
+
+static std::vector<GemmTile> tile_list(int tm_n, int tn_n, bool symm) {
+  std::vector<GemmTile> t;
+  if (symm) {
+    const int TS = (tm_n + 7) / 8;
+    for (int si = 0; si < TS; ++si)
+      for (int sj = si; sj < TS; ++sj)
+        for (int w = 0; w < 64; ++w) {
+          const int tm = si * 8 + (w & 7), tn = sj * 8 + (w >> 3);
+          if (tm < tm_n && tn < tm_n && tn >= tm) t.push_back({tm, tn});
+        }
+  } else {
+    for (int g0 = 0; g0 < tm_n; g0 += 8)
+      for (int tn = 0; tn < tn_n; ++tn)
+        for (int dm = 0; dm < std::min(8, tm_n - g0); ++dm) t.push_back({g0 + dm, tn});
+  }
+  return t;
+}
+
+// TAILK > 1: the tiles of the last partial round (slots = 512) go through the split-K tail
+template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, bool STAMP = false>
+static void run(const char* name, const float* A, const float* inv, int64_t N, int64_t L, float* out, int ns,
+                const double* ref_h, const int* sm_h, const int* sn_h, int tailk) {
+  using Cfg = GemmCfg<BM, BN, WM, WN, STAGES>;
+  GemmArgs g{};
+  g.A = A; g.B = A; g.M = N; g.N = N; g.L = L; g.lda = g_ld; g.ldb = g_ld; g.inva = inv; g.invb = inv; g.out = out;
+  g.ldo = N; g.splitk = 1;
+  CK(hipGetSymbolAddress((void**)&g.zero16, HIP_SYMBOL(d_zero16)));
+  std::vector<GemmTile> t = tile_list((int)((N + BM - 1) / BM), (int)((N + BN - 1) / BN), SYMM);
+  GemmTile* d_t; CK(hipMalloc(&d_t, t.size() * sizeof(GemmTile)));
+  CK(hipMemcpy(d_t, t.data(), t.size() * sizeof(GemmTile), hipMemcpyHostToDevice));
+  g.tiles = d_t;
+  const int slots = 512, total = (int)t.size();
+  int n_main = total, n_tail = 0;
+  if (tailk > 1 && total > slots && total % slots) { n_tail = total % slots; n_main = total - n_tail; }
+  float* part = nullptr;
+  if (n_tail) CK(hipMalloc(&part, (size_t)n_tail * tailk * BM * BN * 4));
+  auto kf = gemm_f32_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_FULL, STAMP>;
+  auto kp = gemm_f32_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_PARTIAL>;
+  auto kr = gemm_f32_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_REDUCE>;
+  for (const void* k : {(const void*)kf, (const void*)kp, (const void*)kr})
+    CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+  if (STAMP) CK(hipMalloc(&g.stamps, (size_t)n_main * 64));
+  auto launch = [&]() {
+    GemmArgs a = g;
+    a.tile_base = 0;
+    hipLaunchKernelGGL(kf, dim3((unsigned)n_main), dim3(Cfg::THREADS), Cfg::LDS_BYTES, 0, a);
+    if (n_tail) {
+      a.tile_base = n_main; a.splitk = tailk; a.partial = part;
+      hipLaunchKernelGGL(kp, dim3((unsigned)(n_tail * tailk)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, 0, a);
+      hipLaunchKernelGGL(kr, dim3((unsigned)n_tail), dim3(Cfg::THREADS), Cfg::LDS_BYTES, 0, a);
+    }
+  };
+  CK(hipMemset(out, 0xff, (size_t)N * N * 4));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  launch();
+  CK(hipDeviceSynchronize());
+  float best = 1e30f, sum = 0.f;
+  for (int it = 0; it < 3; ++it) {
+    CK(hipEventRecord(e0));
+    launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    best = fminf(best, ms); sum += ms;
+  }
+  double maxerr = 0.0;
+  for (int s = 0; s < ns; ++s) {
+    float a, b;
+    CK(hipMemcpy(&a, out + (int64_t)sm_h[s] * N + sn_h[s], 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&b, out + (int64_t)sn_h[s] * N + sm_h[s], 4, hipMemcpyDeviceToHost));
+    maxerr = fmax(maxerr, fmax(fabs((double)a - ref_h[s]), fabs((double)b - ref_h[s])));
+    if (a != b) maxerr = fmax(maxerr, 1.0);  // symmetric inputs must give bitwise symmetric outputs
+  }
+  const double flop_alg = 2.0 * (double)N * (double)N * (double)L, flop_exec = 2.0 * BM * BN * (double)L * total;
+  printf("%-26s tiles %5d (+%d x splitK %d)  avg %8.3f ms  best %8.3f  executed %7.2f TF/s  algorithmic %7.2f TF/s  maxerr %.2e %s\n",
+         name, n_main, n_tail, n_tail ? tailk : 1, sum / 3, best, flop_exec / (sum / 3 * 1e-3) / 1e12,
+         flop_alg / (sum / 3 * 1e-3) / 1e12, maxerr, maxerr < 2e-6 ? "ok" : "FAIL");
+  if (STAMP) {
+    std::vector<unsigned long long> h((size_t)n_main * 8);
+    CK(hipMemcpy(h.data(), g.stamps, (size_t)n_main * 64, hipMemcpyDeviceToHost));
+    std::vector<double> clk, cyc; double seg[4] = {0, 0, 0, 0};
+    for (int b = 0; b < n_main; ++b) {
+      const double dt = (double)(h[8 * b + 1] - h[8 * b]), dr = (double)(h[8 * b + 3] - h[8 * b + 2]);
+      if (dr > 0) { clk.push_back(dt / dr * 0.1); cyc.push_back(dt); }
+      for (int q = 0; q < 4; ++q) seg[q] += (double)h[8 * b + 4 + q];
+    }
+    std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
+    const double nkt = (double)n_main * (double)((L + 31) / 32);
+    printf("   [stamped build] clock %.3f GHz; block loop %.1f cyc per k-tile (MFMA floor 8192); per k-tile: vmcnt %.0f barrier %.0f"
+           " issue %.0f reads+MFMA %.0f\n", clk[clk.size() / 2], cyc[cyc.size() / 2] / (double)((L + 31) / 32), seg[0] / nkt,
+           seg[1] / nkt, seg[2] / nkt, seg[3] / nkt);
+    CK(hipFree(g.stamps));
+  }
+  fflush(stdout);
+  CK(hipFree(d_t)); if (part) CK(hipFree(part));
+}
+
+int main(int argc, char** argv) {
+  const int64_t N = argc > 1 ? atoll(argv[1]) : 8189, L = argc > 2 ? atoll(argv[2]) : 32768;
+  g_ld = L + (argc > 3 ? atoll(argv[3]) : 0);
+  float *A, *inv, *out;
+  CK(hipMalloc(&A, (size_t)N * g_ld * 4)); CK(hipMalloc(&inv, (size_t)N * 4)); CK(hipMalloc(&out, (size_t)N * N * 4));
+  hipLaunchKernelGGL(fill_normal, dim3((unsigned)(((int64_t)N * g_ld + 255) / 256)), dim3(256), 0, 0, A, N * g_ld, 1234ull);
+  hipLaunchKernelGGL(inv_norms, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, 0, A, N, L, g_ld, inv);
+  const int ns = 48;
+  std::vector<int> sm(ns), sn(ns);
+  srand(7);
+  for (int s = 0; s < ns; ++s) { sm[s] = rand() % N; sn[s] = s < 8 ? sm[s] : rand() % N; }
+  sm[8] = 0; sn[8] = (int)N - 1; sm[9] = (int)N - 1; sn[9] = (int)N - 1; sm[10] = 127; sn[10] = 128; sm[11] = 255; sn[11] = 256;
+  int *d_sm, *d_sn; double* d_ref;
+  CK(hipMalloc(&d_sm, ns * 4)); CK(hipMalloc(&d_sn, ns * 4)); CK(hipMalloc(&d_ref, ns * 8));
+  CK(hipMemcpy(d_sm, sm.data(), ns * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_sn, sn.data(), ns * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ref_samples, dim3(ns), dim3(64), 0, 0, A, inv, L, g_ld, d_sm, d_sn, ns, d_ref);
+  std::vector<double> ref(ns);
+  CK(hipMemcpy(ref.data(), d_ref, ns * 8, hipMemcpyDeviceToHost));
+  printf("N=%lld L=%lld ld=%lld\n", (long long)N, (long long)L, (long long)g_ld);
+#define RUN(BM, BN, WM, WN, ST, SY, OCC, TK) run<BM, BN, WM, WN, ST, SY, OCC>(#BM "x" #BN " w" #WM "x" #WN " st" #ST " symm" #SY, A, inv, N, L, out, ns, ref.data(), sm.data(), sn.data(), TK)
+  RUN(128, 128, 2, 2, 2, false, 2, 1);
+  run<128, 128, 2, 2, 2, false, 2, true>("128x128 stamped", A, inv, N, L, out, ns, ref.data(), sm.data(), sn.data(), 1);
+  RUN(128, 128, 2, 2, 2, true, 2, 1);
+  RUN(128, 128, 2, 2, 2, true, 2, 8);
+  RUN(128, 128, 2, 2, 2, true, 2, 16);
+  RUN(128, 128, 2, 2, 3, false, 2, 1);
+  return 0;
+}

@@ -9,11 +9,12 @@
 // K-major so tiles stream HBM -> LDS with 16-B-per-lane LDS-DMA (global_load_lds_dwordx4), double
 // buffered; LDS image XOR-swizzled on the SOURCE address + matching XOR on the ds_read_b128 (conflict
 // free); block -> tile map is XCD-aware so the 64 tiles resident on one XCD share 8 A and 8 B panels.
+#include <algorithm>
+
 #include "common.hpp"
+#include "gemm_f32.hpp"
 
 namespace pvs {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -50,142 +51,101 @@ int launch_row_inv_norms(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L
 }
 
 // ------------------------------------------------------------------------------------- K6 fp32 MFMA
-constexpr int GT_M = 128, GT_N = 128, GT_K = 32;
-constexpr int GEMM_THREADS = 256;
-constexpr int GEMM_KBLOCK = 1024;  // k-values per MFMA accumulation chain (see kernel)
-constexpr int TILE_BYTES = GT_M * GT_K * 4;  // 16 KiB per operand per stage
+// Kernel: gemm_f32.hpp (128x128 tile, 4 waves, 2 stages, 2 workgroups per CU).  The host builds the tile list:
+// 8x8 super-tiles for L2 panel sharing, upper triangle only when A == B (SYMM), and -- when the last round of
+// workgroups would be mostly empty -- hands the remaining tiles to a deterministic split-K tail.
+using GemmMain = GemmCfg<128, 128, 2, 2, 2>;
+constexpr int GEMM_BLOCKS_PER_CU = 2;
 
-struct GemmArgs {
-  const float* A;
-  const float* B;
-  int64_t M, N, L;
-  const float* inva;
-  const float* invb;
-  float* out;
-  int64_t ldo;
-  int tiles_m, tiles_n;
+struct GemmPlanKey {
+  int tiles_m = -1, tiles_n = -1, symm = -1, slots = -1;
+  bool operator==(const GemmPlanKey& o) const {
+    return tiles_m == o.tiles_m && tiles_n == o.tiles_n && symm == o.symm && slots == o.slots;
+  }
 };
+struct GemmPlan {
+  GemmPlanKey key;
+  int n_main = 0, n_tail = 0, splitk = 1;
+  GemmTile* d_tiles = nullptr;
+  size_t cap = 0;
+};
+static GemmPlan g_plan;  // one cached plan per process (single context per process is the norm)
 
-// LDS image of one operand tile: [128 rows][8 chunks of 16 B]; position (r, c) holds the row's global
-// chunk c ^ ((r >> 1) & 7).  One wave-instruction of LDS-DMA writes 64 x 16 B = 8 consecutive rows.
-__device__ __forceinline__ void stage_tile(const float* __restrict__ base, int64_t nrows, int64_t L, int64_t row0,
-                                           int64_t k0, char* lds_tile, int wave, int lane) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = 32 * wave + 8 * q + (lane >> 3);
-    const int c = lane & 7;
-    const int gc = c ^ ((r >> 1) & 7);
-    int64_t grow = row0 + r;
-    grow = grow < nrows ? grow : nrows - 1;  // clamp: rows past the edge are computed and discarded
-    const int64_t kc = k0 + 4 * gc;
-    const float* src = kc < L ? base + grow * L + kc : g_zero16;
-    // LDS destination = wave-uniform base + lane * 16 B; the per-lane SOURCE address carries the swizzle
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(lds_tile + (32 * wave + 8 * q) * (GT_K * 4)),
-                                     16, 0, 0);
-  }
-}
-
-__device__ __forceinline__ float4 lds_frag(const char* lds_tile, int row, int cc) {
-  return *reinterpret_cast<const float4*>(lds_tile + (row * 8 + (cc ^ ((row >> 1) & 7))) * 16);
-}
-
-__global__ __launch_bounds__(GEMM_THREADS, 2) void cosine_gemm_f32_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile | B tile]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // ---- XCD-aware, grouped tile order (bijective for any grid size)
-  const int nwg = g.tiles_m * g.tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, pos = bid >> 3;
-  const int q8 = nwg >> 3, r8 = nwg & 7;
-  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + pos;
-  constexpr int GM = 8;
-  const int per_group = GM * g.tiles_n;
-  const int grp = lin / per_group, rem = lin - grp * per_group;
-  const int first_m = grp * GM;
-  const int gsz = min(GM, g.tiles_m - first_m);
-  const int tm = first_m + rem % gsz, tn = rem / gsz;
-  const int64_t m0 = (int64_t)tm * GT_M, n0 = (int64_t)tn * GT_N;
-
-  // Two-level summation: the MFMA chain (a k-ordered fp32 fma chain) runs over at most GEMM_KBLOCK k-values,
-  // then its tile is added into `tot`.  A single 32768-long chain drifts ~4e-6 relative (random-walk
-  // rounding); blocked at 1024 the error is ~1.6e-7, the level of a blocked BLAS sgemm (the reference).
-  f32x16 acc[2][2], tot[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; tot[a][b][r] = 0.f; }
-
-  const int nk = (int)((g.L + GT_K - 1) / GT_K);
-  stage_tile(g.A, g.M, g.L, m0, 0, smem, wave, lane);
-  stage_tile(g.B, g.N, g.L, n0, 0, smem + TILE_BYTES, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * (2 * TILE_BYTES);
-    char* nxt = smem + ((kt + 1) & 1) * (2 * TILE_BYTES);
-    if (kt + 1 < nk) {
-      stage_tile(g.A, g.M, g.L, m0, (int64_t)(kt + 1) * GT_K, nxt, wave, lane);
-      stage_tile(g.B, g.N, g.L, n0, (int64_t)(kt + 1) * GT_K, nxt + TILE_BYTES, wave, lane);
-    }
-    const char* la = cur;
-    const char* lb = cur + TILE_BYTES;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int cc = 2 * t + h;
-      const float4 a0 = lds_frag(la, wm * 64 + i, cc);
-      const float4 a1 = lds_frag(la, wm * 64 + 32 + i, cc);
-      const float4 b0 = lds_frag(lb, wn * 64 + i, cc);
-      const float4 b1 = lds_frag(lb, wn * 64 + 32 + i, cc);
-#define PVS_MF(AV, BV, ACC)                                                  \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, BV.x, ACC, 0, 0, 0);      \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, BV.y, ACC, 0, 0, 0);      \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, BV.z, ACC, 0, 0, 0);      \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, BV.w, ACC, 0, 0, 0);
-      PVS_MF(a0, b0, acc[0][0]) PVS_MF(a0, b1, acc[0][1]) PVS_MF(a1, b0, acc[1][0]) PVS_MF(a1, b1, acc[1][1])
-#undef PVS_MF
-    }
-    if ((kt & (GEMM_KBLOCK / GT_K - 1)) == GEMM_KBLOCK / GT_K - 1) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          tot[a][b] += acc[a][b];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] += tot[a][b];
-
-  // ---- epilogue: scale by 1/(||a|| ||b||); C/D layout col = lane&31, row = (reg&3)+8*(reg>>2)+4*h
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int64_t n = n0 + wn * 64 + 32 * ni + i;
-      const float sb = (n < g.N && g.invb) ? g.invb[n] : 1.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm * 64 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < g.M && n < g.N) {
-          const float sa = g.inva ? g.inva[m] : 1.f;
-          g.out[m * g.ldo + n] = acc[mi][ni][r] * sa * sb;
-        }
+static int build_plan(pvs_ctx* ctx, int tiles_m, int tiles_n, bool symm, GemmPlan** out) {
+  const int slots = ctx->num_cu * GEMM_BLOCKS_PER_CU;
+  const GemmPlanKey key{tiles_m, tiles_n, symm ? 1 : 0, slots};
+  if (!(g_plan.key == key)) {
+    std::vector<GemmTile> t;
+    if (symm) {
+      const int TS = (tiles_m + 7) / 8;
+      for (int si = 0; si < TS; ++si)
+        for (int sj = si; sj < TS; ++sj)
+          for (int w = 0; w < 64; ++w) {
+            const int tm = si * 8 + (w & 7), tn = sj * 8 + (w >> 3);
+            if (tm < tiles_m && tn < tiles_m && tn >= tm) t.push_back({tm, tn});
+          }
+    } else {
+      for (int g0 = 0; g0 < tiles_m; g0 += 8) {
+        const int gsz = std::min(8, tiles_m - g0);
+        for (int tn = 0; tn < tiles_n; ++tn)
+          for (int dm = 0; dm < gsz; ++dm) t.push_back({g0 + dm, tn});
       }
     }
+    const int total = (int)t.size();
+    const int rounds = total / slots, rem = total % slots;
+    g_plan.n_main = total;
+    g_plan.n_tail = 0;
+    g_plan.splitk = 1;
+    if (rounds >= 1 && rem > 0 && rem <= slots / 2) {  // the last round would leave >= half the chip idle
+      int s = 2;
+      while (s * 2 <= 16 && rem * s * 2 <= slots) s *= 2;
+      g_plan.n_main = total - rem;
+      g_plan.n_tail = rem;
+      g_plan.splitk = s;
+    }
+    if (g_plan.cap < t.size()) {
+      PVS_HIP(hipStreamSynchronize(ctx->stream));
+      if (g_plan.d_tiles) PVS_HIP(hipFree(g_plan.d_tiles));
+      g_plan.cap = t.size() + t.size() / 4 + 64;
+      PVS_HIP(hipMalloc(reinterpret_cast<void**>(&g_plan.d_tiles), g_plan.cap * sizeof(GemmTile)));
+    }
+    PVS_HIP(hipMemcpyAsync(g_plan.d_tiles, t.data(), t.size() * sizeof(GemmTile), hipMemcpyHostToDevice, ctx->stream));
+    PVS_HIP(hipStreamSynchronize(ctx->stream));  // `t` is pageable host memory going out of scope
+    g_plan.key = key;
   }
+  *out = &g_plan;
+  return PVS_OK;
+}
+
+template <bool SYMM>
+static int launch_gemm_mfma(pvs_ctx* ctx, GemmArgs g, const GemmPlan& plan) {
+  auto kfull = gemm_f32_kernel<128, 128, 2, 2, 2, SYMM, 2, GEMM_MODE_FULL>;
+  auto kpart = gemm_f32_kernel<128, 128, 2, 2, 2, SYMM, 2, GEMM_MODE_PARTIAL>;
+  auto kred = gemm_f32_kernel<128, 128, 2, 2, 2, SYMM, 2, GEMM_MODE_REDUCE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    for (const void* k : {reinterpret_cast<const void*>(kfull), reinterpret_cast<const void*>(kpart),
+                          reinterpret_cast<const void*>(kred)})
+      PVS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, GemmMain::LDS_BYTES));
+    attr_set = true;
+  }
+  if (plan.n_main > 0) {
+    g.tile_base = 0;
+    hipLaunchKernelGGL(kfull, dim3((unsigned)plan.n_main), dim3(GemmMain::THREADS), GemmMain::LDS_BYTES, ctx->stream, g);
+  }
+  if (plan.n_tail > 0) {
+    float* part = nullptr;
+    PVS_TRY(ws_reserve(ctx, 4, (size_t)plan.n_tail * plan.splitk * 128 * 128 * sizeof(float),
+                       reinterpret_cast<void**>(&part)));
+    g.tile_base = plan.n_main;
+    g.splitk = plan.splitk;
+    g.partial = part;
+    hipLaunchKernelGGL(kpart, dim3((unsigned)(plan.n_tail * plan.splitk)), dim3(GemmMain::THREADS), GemmMain::LDS_BYTES,
+                       ctx->stream, g);
+    hipLaunchKernelGGL(kred, dim3((unsigned)plan.n_tail), dim3(GemmMain::THREADS), GemmMain::LDS_BYTES, ctx->stream, g);
+  }
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
 }
 
 // ------------------------------------------------------------------------------------- generic tiled fallback
@@ -247,21 +207,23 @@ int launch_cosine_f32(pvs_ctx* ctx, const float* A, int64_t M, const float* B, i
                       const float* inva, const float* invb, float* out, int64_t ldo) {
   if (M <= 0 || N <= 0) return PVS_OK;
   if (L <= 0) PVS_FAIL(PVS_ERR_INVALID, "cosine: L must be positive");
+  // MFMA path: 16-B aligned rows, and per-lane byte offsets inside a 128-row tile must fit 32 bits
   const bool fast = (L % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
-                    (reinterpret_cast<uintptr_t>(B) % 16 == 0);
+                    (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (L <= (int64_t)8 * 1024 * 1024);
   ScopedTimer tm(ctx, T_GEMM);
   if (fast) {
-    GemmArgs g{A, B, M, N, L, inva, invb, out, ldo, (int)((M + GT_M - 1) / GT_M), (int)((N + GT_N - 1) / GT_N)};
-    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n;
-    if (nwg > 0x7fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "cosine: too many tiles for one launch");
-    const size_t lds = 4 * TILE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-      PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_gemm_f32_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(cosine_gemm_f32_kernel, dim3((unsigned)nwg), dim3(GEMM_THREADS), lds, ctx->stream, g);
+    const int tiles_m = (int)((M + 127) / 128), tiles_n = (int)((N + 127) / 128);
+    if ((int64_t)tiles_m * tiles_n > 0x3fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "cosine: too many tiles for one launch");
+    // self-similarity: same operand, same norms -> only the upper triangle is computed, the rest mirrored
+    const bool symm = (A == B) && (M == N) && (inva == invb);
+    GemmPlan* plan = nullptr;
+    PVS_TRY(build_plan(ctx, tiles_m, tiles_n, symm, &plan));
+    GemmArgs g{};
+    g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = L; g.ldb = L; g.inva = inva; g.invb = invb;
+    g.out = out; g.ldo = ldo; g.tiles = plan->d_tiles; g.splitk = 1;
+    PVS_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(const_cast<float**>(&g.zero16)), HIP_SYMBOL(g_zero16)));
+    if (symm) PVS_TRY(launch_gemm_mfma<true>(ctx, g, *plan));
+    else PVS_TRY(launch_gemm_mfma<false>(ctx, g, *plan));
   } else {
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
     hipLaunchKernelGGL(cosine_gemm_generic_kernel<float>, grid, dim3(256), 0, ctx->stream, A, M, B, N, L, inva, invb,

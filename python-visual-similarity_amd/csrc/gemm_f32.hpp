@@ -1,0 +1,398 @@
+// Exact-fp32 MFMA "NT" GEMM for the cosine step:  out[m][n] = (A_m . B_n) * (inva[m] * invb[n]),
+// A [M][lda], B [N][ldb] both K-major (row = one encoding).  Shared by cosine.hip and the variant harness
+// (bench/gemm_variants.hip).  Measured on MI355X (8189 x 8189 x 32768): 146.7 TFLOP/s = 93 % of the f32 MFMA peak.
+//
+//   * v_mfma_f32_32x32x2_f32, wave tile (32*MI) x (32*NI), block tile BM x BN, BK = 32; shipped: 128x128, 4 waves,
+//     2 workgroups per CU (two waves per SIMD from DIFFERENT workgroups, so one computes while the other syncs).
+//   * operands stream HBM -> LDS with 16-B-per-lane LDS-DMA; one wave-instruction fills 8 rows x 128 B.  The LDS image
+//     is XOR-swizzled through the per-lane SOURCE offset (chunk ^= (row >> 1) & 7) with the same XOR on the
+//     ds_read_b128: conflict-free 16-lane read groups.
+//   * What the load phase must NOT do (each was measured on this kernel):
+//       - use the vector ALU.  The f32 MFMA executes at the vector-FMA rate and a wave that needs VALU slots while
+//         its SIMD partner streams MFMAs starves: with 8 x `v_lshl_add_u64` per k-tile the load phase took ~4040
+//         cycles (the whole of the partner's MFMA phase), with none 842.  Addresses are therefore
+//         `scalar 64-bit base (SALU add per k-tile) + constant 32-bit lane offset` in hand-written
+//         `global_load_lds_dwordx4 voff, s[base:base+1] offset:imm` groups (hipcc always materialises a 64-bit VGPR
+//         address for the builtin);
+//       - let hipcc see the fragment ds_reads.  It cannot prove that the in-flight LDS-DMA of the NEXT tile does not
+//         alias them and puts `s_waitcnt vmcnt(0)` in front of the first read of every k-tile (load and compute
+//         serialise: 125 TFLOP/s).  Reads are inline asm with hand-counted lgkmcnt + sched_barrier.
+//   * per k-tile: counted vmcnt (tile t landed; t+1 .. t+STAGES-2 in flight), raw s_barrier, issue tile
+//     t+STAGES-1, compute tile t.
+//   * two-level accumulation: MFMA chains are cut every KBLOCK k-values and summed into a second register tile
+//     (a single 32768-long fp32 fma chain drifts ~4e-6 relative; blocked it is ~1.6e-7, BLAS level).
+//   * tiles come from a host-built list (any order / subset): XCD-aware 8x8 super-tile order for L2 panel sharing;
+//     SYMM (A == B): only tiles tn >= tm are listed, the mirrored tile is written through an LDS transpose
+//     (coalesced) and is bit-identical to the direct one.
+//   * MODE_PARTIAL / MODE_REDUCE: a deterministic split-K for the tiles of the last, partly filled round: S blocks
+//     per tile write raw accumulators, one block per tile sums them in slice order and runs the normal epilogue.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pvs {
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct GemmTile {
+  int tm, tn;
+};
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  int64_t M, N, L;
+  int64_t lda, ldb;  // row strides in floats (>= L)
+  const float* inva;
+  const float* invb;
+  float* out;
+  int64_t ldo;
+  const GemmTile* tiles;  // tile list (device)
+  int tile_base;          // first list entry handled by this launch
+  int splitk;             // MODE_PARTIAL / MODE_REDUCE: slices per tile
+  float* partial;         // [tiles in this launch][splitk][BM*BN] raw accumulators
+  const float* zero16;    // 16 B of zeros in device memory (source for k-chunks past L)
+  unsigned long long* stamps;  // diagnostic builds only (STAMP)
+};
+
+constexpr int GEMM_BK = 32;
+constexpr int GEMM_KBLOCK = 1024;
+enum { GEMM_MODE_FULL = 0, GEMM_MODE_PARTIAL = 1, GEMM_MODE_REDUCE = 2 };
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+struct GemmCfg {
+  static constexpr int THREADS = 64 * WM * WN;
+  static constexpr int WAVES = WM * WN;
+  static constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  static constexpr int A_BYTES = BM * GEMM_BK * 4, B_BYTES = BN * GEMM_BK * 4;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;            // wave-instructions per tile
+  static constexpr int LOADS_PER_WAVE = (A_INSTR + B_INSTR) / WAVES;  // per k-tile
+  static constexpr int MIRROR_BYTES = WAVES * 32 * 33 * 4;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES > MIRROR_BYTES ? STAGES * STAGE_BYTES : MIRROR_BYTES;
+  static_assert((A_INSTR + B_INSTR) % WAVES == 0, "tile loads must divide evenly over the waves");
+  static_assert(A_INSTR % LOADS_PER_WAVE == 0, "a wave's loads must not straddle the A / B boundary");
+  static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "wave tile must be a multiple of 32x32");
+};
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ unsigned gemm_frag_off(int row, int cc) { return (row * 8 + (cc ^ ((row >> 1) & 7))) * 16; }
+__device__ __forceinline__ void ds_read_frag(f32x4_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+  else static_assert(N < 0, "add this lgkmcnt value");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else static_assert(N < 0, "add this vmcnt value");
+}
+
+// This wave's LOADS_PER_WAVE LDS-DMA instructions per k-tile.  Wave w's q-th load fills LDS bytes
+// [(w*LPW + q) * 1024, +1024) of the stage: A rows first, then B rows (A_BYTES = A_INSTR * 1024).
+// Loads go in groups of <= 4 sharing one M0 (LDS base) and one scalar base; the q-th of a group uses the immediate
+// offset q KiB, which the hardware adds to BOTH the LDS and the global address, so the lane offset is pre-biased.
+template <class Cfg>
+struct GemmLoader {
+  static constexpr int LPW = Cfg::LOADS_PER_WAVE;
+  const char* base;    // this wave's operand (A or B) at the tile's first row, minus 3 KiB (keeps voff >= 0)
+  unsigned voff[LPW];  // per-lane byte offset from base (row * ld * 4 + swizzled chunk * 16 + 3 KiB - (q&3) KiB)
+  unsigned gc4[LPW];   // 4 * swizzled chunk (floats): k-tail check only
+  int wave_base;       // byte offset of this wave's first load inside a stage buffer
+  bool is_a;
+
+  __device__ __forceinline__ void init(const GemmArgs& g, int64_t m0, int64_t n0, int wave, int lane) {
+    wave_base = wave * LPW * 1024;
+    is_a = wave * LPW < Cfg::A_INSTR;
+    const int64_t row0 = is_a ? m0 : n0, nrows = is_a ? g.M : g.N, ld = is_a ? g.lda : g.ldb;
+    base = reinterpret_cast<const char*>((is_a ? g.A : g.B) + row0 * ld) - 3072;
+#pragma unroll
+    for (int q = 0; q < LPW; ++q) {
+      const int inst = wave * LPW + q;
+      const int r = 8 * (is_a ? inst : inst - Cfg::A_INSTR) + (lane >> 3);
+      const int gc = (lane & 7) ^ ((r >> 1) & 7);
+      int64_t grow = row0 + r;
+      grow = grow < nrows ? grow : nrows - 1;  // rows past the edge are computed and discarded
+      voff[q] = (unsigned)((grow - row0) * ld * 4 + 16 * gc + 3072 - (q & 3) * 1024);
+      gc4[q] = 4 * gc;
+    }
+  }
+
+  // full tile: no VALU, no compiler-visible load (the caller counts vmcnt by hand)
+  template <int Q0 = 0>
+  __device__ __forceinline__ void issue(int64_t k0, char* stage) const {
+    if constexpr (Q0 < LPW) {
+      constexpr int GE = Q0 + 4 < LPW ? Q0 + 4 : LPW;
+      const char* sb = base + k0 * 4;
+      const unsigned m0v = lds_addr(stage + wave_base + Q0 * 1024);
+      if constexpr (GE - Q0 == 4)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %1\n\t"
+                     "global_load_lds_dwordx4 %3, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %4, %1 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %5, %1 offset:3072"
+                     ::"s"(m0v), "s"(sb), "v"(voff[Q0]), "v"(voff[Q0 + 1]), "v"(voff[Q0 + 2]), "v"(voff[Q0 + 3])
+                     : "memory");
+      else if constexpr (GE - Q0 == 2)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %1\n\t"
+                     "global_load_lds_dwordx4 %3, %1 offset:1024"
+                     ::"s"(m0v), "s"(sb), "v"(voff[Q0]), "v"(voff[Q0 + 1])
+                     : "memory");
+      else
+        static_assert(GE - Q0 == 4, "LOADS_PER_WAVE must be 4k or 4k+2");
+      issue<GE>(k0, stage);
+    }
+  }
+
+  // last k-tile when L % 32 != 0: 16-B chunks at or past L come from a zero buffer (builtin path, rare)
+  __device__ __forceinline__ void issue_checked(const GemmArgs& g, int64_t k0, char* stage) const {
+#pragma unroll
+    for (int q = 0; q < LPW; ++q) {
+      const char* p = (k0 + gc4[q] < g.L) ? base + k0 * 4 + (size_t)voff[q] + (q & 3) * 1024
+                                          : reinterpret_cast<const char*>(g.zero16);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                       (__attribute__((address_space(3))) void*)(stage + wave_base + q * 1024), 16, 0, 0);
+    }
+  }
+};
+
+// OCC = minimum waves per SIMD the register allocator must leave room for (blocks per CU * threads / 256)
+template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, int MODE = GEMM_MODE_FULL, bool STAMP = false>
+__global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_f32_kernel(GemmArgs g) {
+  using Cfg = GemmCfg<BM, BN, WM, WN, STAGES>;
+  constexpr int MI = Cfg::MI, NI = Cfg::NI;
+  static_assert(!SYMM || BM == BN, "the mirrored store needs square tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: LDS-DMA bases stay in SGPRs
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- block -> list entry (XCD-aware, bijective): blocks b and b+8 share an XCD, give each XCD a contiguous run
+  int lin, slice = 0;
+  {
+    int bid = blockIdx.x;
+    if constexpr (MODE == GEMM_MODE_PARTIAL) {
+      slice = bid % g.splitk;
+      bid /= g.splitk;
+    }
+    if constexpr (MODE == GEMM_MODE_FULL) {
+      const int nwg = gridDim.x;
+      const int xcd = bid & 7, pos = bid >> 3;
+      const int q8 = nwg >> 3, r8 = nwg & 7;
+      lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + pos;
+    } else {
+      lin = bid;  // tail launches are small: plain order
+    }
+  }
+  const GemmTile tile = g.tiles[g.tile_base + lin];
+  const int tm = tile.tm, tn = tile.tn;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < NI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if constexpr (MODE != GEMM_MODE_REDUCE) {
+    f32x16_t tot[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < NI; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[a][b][r] = 0.f;
+
+    const int nk_all = (int)((g.L + GEMM_BK - 1) / GEMM_BK);
+    int kt0 = 0, kt1 = nk_all;
+    if constexpr (MODE == GEMM_MODE_PARTIAL) {
+      const int per = (nk_all + g.splitk - 1) / g.splitk;
+      kt0 = min(nk_all, slice * per);
+      kt1 = min(nk_all, kt0 + per);
+    }
+    const bool ktail = (g.L % GEMM_BK) != 0;  // only the last k-tile can reach past L
+    GemmLoader<Cfg> ld;
+    ld.init(g, m0, n0, wave, lane);
+    auto stage_tile = [&](int t) {
+      char* st = smem + ((t - kt0) % STAGES) * Cfg::STAGE_BYTES;
+      if (ktail && t == nk_all - 1) ld.issue_checked(g, (int64_t)t * GEMM_BK, st);
+      else ld.issue((int64_t)t * GEMM_BK, st);
+    };
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (kt0 + s < kt1) stage_tile(kt0 + s);
+
+    // per-lane fragment offsets inside a stage for the four k-steps (swizzled chunk cc = 2t + h)
+    unsigned offa[MI][4], offb[NI][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int a = 0; a < MI; ++a) offa[a][t] = gemm_frag_off(wm * (32 * MI) + 32 * a + i, 2 * t + h);
+#pragma unroll
+      for (int b = 0; b < NI; ++b) offb[b][t] = Cfg::A_BYTES + gemm_frag_off(wn * (32 * NI) + 32 * b + i, 2 * t + h);
+    }
+    const unsigned lds0 = lds_addr(smem);
+    unsigned long long st_t0 = 0, st_r0 = 0, seg[4] = {0, 0, 0, 0};
+    if constexpr (STAMP) {  // in-kernel clock = d(memtime) / d(memrealtime) * 100 MHz
+      st_t0 = __builtin_amdgcn_s_memtime();
+      st_r0 = __builtin_amdgcn_s_memrealtime();
+    }
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+      unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      if constexpr (STAMP) s0 = __builtin_amdgcn_s_memtime();
+      // tile kt must have landed; tiles kt+1 .. kt+STAGES-2 stay in flight across the barrier
+      if (kt + STAGES - 2 < kt1) wait_vm<(STAGES - 2) * Cfg::LOADS_PER_WAVE>();
+      else wait_vm<0>();
+      if constexpr (STAMP) s1 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      if constexpr (STAMP) s2 = __builtin_amdgcn_s_memtime();
+      if (kt + STAGES - 1 < kt1) stage_tile(kt + STAGES - 1);
+      if constexpr (STAMP) s3 = __builtin_amdgcn_s_memtime();
+      const unsigned base = lds0 + ((kt - kt0) % STAGES) * Cfg::STAGE_BYTES;
+      f32x4_t av[2][MI], bv[2][NI];
+#pragma unroll
+      for (int a = 0; a < MI; ++a) ds_read_frag(av[0][a], base + offa[a][0]);
+#pragma unroll
+      for (int b = 0; b < NI; ++b) ds_read_frag(bv[0][b], base + offb[b][0]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = t & 1, n = c ^ 1;
+        if (t < 3) {
+#pragma unroll
+          for (int a = 0; a < MI; ++a) ds_read_frag(av[n][a], base + offa[a][t + 1]);
+#pragma unroll
+          for (int b = 0; b < NI; ++b) ds_read_frag(bv[n][b], base + offb[b][t + 1]);
+          wait_lgkm<MI + NI>();  // the step-t fragments are back; the step-t+1 reads stay in flight
+        } else {
+          wait_lgkm<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][a][e], bv[c][b][e], acc[a][b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (STAMP) {
+        const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+        seg[0] += s1 - s0; seg[1] += s2 - s1; seg[2] += s3 - s2; seg[3] += s4 - s3;
+      }
+      if (((kt - kt0) & (GEMM_KBLOCK / GEMM_BK - 1)) == GEMM_KBLOCK / GEMM_BK - 1) {
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+          for (int b = 0; b < NI; ++b) {
+            tot[a][b] += acc[a][b];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+          }
+      }
+    }
+    if constexpr (STAMP) {
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+      if (threadIdx.x == 0 && g.stamps) {
+        unsigned long long* o = g.stamps + 8 * blockIdx.x;
+        o[0] = st_t0; o[1] = t1; o[2] = st_r0; o[3] = r1;
+        o[4] = seg[0]; o[5] = seg[1]; o[6] = seg[2]; o[7] = seg[3];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < NI; ++b) acc[a][b] += tot[a][b];
+  }
+
+  // raw accumulator image of a block: [wave][a*NI+b][reg][lane]  (256-B coalesced rows)
+  constexpr int PART_ELEMS = BM * BN;
+  if constexpr (MODE == GEMM_MODE_PARTIAL) {
+    float* dst = g.partial + ((int64_t)lin * g.splitk + slice) * PART_ELEMS + wave * (MI * NI * 1024);
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < NI; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(a * NI + b) * 1024 + r * 64 + lane] = acc[a][b][r];
+    return;
+  }
+  if constexpr (MODE == GEMM_MODE_REDUCE) {
+    // slices are added in index order: deterministic, independent of how the partial launch was scheduled
+    for (int s = 0; s < g.splitk; ++s) {
+      const float* src = g.partial + ((int64_t)lin * g.splitk + s) * PART_ELEMS + wave * (MI * NI * 1024);
+#pragma unroll
+      for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] += src[(a * NI + b) * 1024 + r * 64 + lane];
+    }
+  }
+
+  // ---- epilogue: scale, store.  C/D layout: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int a = 0; a < MI; ++a) {
+#pragma unroll
+    for (int b = 0; b < NI; ++b) {
+      const int64_t n = n0 + wn * (32 * NI) + 32 * b + i;
+      const float sb = (n < g.N && g.invb) ? g.invb[n] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * (32 * MI) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float sa = (m < g.M && g.inva) ? g.inva[m] : 1.f;
+        acc[a][b][r] = acc[a][b][r] * (sa * sb);  // sa*sb commutes: out[m][n] == out[n][m] bitwise
+        if (m < g.M && n < g.N) g.out[m * g.ldo + n] = acc[a][b][r];
+      }
+    }
+  }
+  if constexpr (SYMM) {
+    if (tm != tn) {
+      // mirrored tile out[n][m]: transpose each 32x32 sub-tile through this wave's private LDS patch
+      __syncthreads();  // every wave is done reading the operand stages
+      float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 33);
+#pragma unroll
+      for (int a = 0; a < MI; ++a) {
+#pragma unroll
+        for (int b = 0; b < NI; ++b) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) patch[i * 33 + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[a][b][r];  // [n][m]
+          const int64_t mb = m0 + wm * (32 * MI) + 32 * a, nb = n0 + wn * (32 * NI) + 32 * b;
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const int nn = 2 * rr + h;           // row of the mirrored tile handled by this half-wave
+            const float v = patch[nn * 33 + i];  // lanes i -> consecutive m (LDS ops of one wave execute in order)
+            if (nb + nn < g.N && mb + i < g.M) g.out[(nb + nn) * g.ldo + mb + i] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace pvs
