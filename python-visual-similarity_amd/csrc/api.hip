@@ -597,8 +597,13 @@ PVS_EXPORT int pvs_cosine_topk_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, c
   PVS_HIP(hipSetDevice(ctx->device));
   if (N == 0) return launch_topk(ctx, nullptr, nq, 0, 0, k, col_offset, merge, d_idx, d_val);
   PVS_NEED(d_DB, "DB");
-  // score panel: at most 8192 x 32768 fp32 = 1 GiB, written by the GEMM and consumed by the select
-  const int64_t QT = std::min<int64_t>(nq, 8192), NC = std::min<int64_t>(N, 32768);
+  // score panel: at most 8192 x 32768 fp32 = 1 GiB, written by the GEMM and consumed by the select.
+  // Ranking deeper than 1024 pages through complete rows, so the panel then spans all N columns.
+  const bool deep = k > 1024;
+  if (deep && (merge || N > (int64_t)1 << 28)) PVS_FAIL(PVS_ERR_UNSUPPORTED, "ranking depth %d needs a single panel", k);
+  const int64_t NC = deep ? N : std::min<int64_t>(N, 32768);
+  const int64_t QT = deep ? std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 28) / N))
+                          : std::min<int64_t>(nq, 8192);
   float* panel = nullptr;
   PVS_TRY(ws_reserve(ctx, 2, (size_t)QT * NC * sizeof(float), reinterpret_cast<void**>(&panel)));
   for (int64_t q0 = 0; q0 < nq; q0 += QT) {

@@ -8,6 +8,8 @@
 // row are distinct, larger key = better).  A panel is consumed in chunks of 8192 columns held in registers
 // together with the running list; the k best are found by an MSB-first 8-bit radix SELECT (LDS histogram,
 // early exit when the pivot bin is taken whole), compacted, and only the final list is sorted (bitonic).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace pvs {
@@ -40,8 +42,10 @@ struct TopkArgs {
   int64_t col_offset;
   int merge;
   int n_lists;              // > 0 selects list mode (ncols = n_lists * k)
-  int64_t* idx;             // [nq][k]
-  float* val;               // [nq][k]
+  int64_t* idx;             // [nq][out_ld]; this launch writes columns [out_off, out_off + k)
+  float* val;
+  int64_t out_ld;
+  int out_off;              // > 0: paging -- only candidates strictly worse than entry out_off-1 are eligible
 };
 
 // block-wide inclusive scan of one int per thread (256 threads); tmp: LDS int[4]
@@ -71,16 +75,24 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkArgs a) {
   const int k = a.k;
   int cur = 0;
   int run_count = 0;
+  int64_t* const oidx = a.idx + q * a.out_ld + a.out_off;
+  float* const oval = a.val + q * a.out_ld + a.out_off;
+  // paging (ranking deeper than TK_KMAX): everything at or above the previous page's last key is already placed
+  uint64_t upper = ~0ull;
+  if (a.out_off > 0) {
+    const int64_t pid = oidx[-1];
+    upper = pid >= 0 ? make_key(oval[-1], (uint32_t)pid) : 0ull;   // previous page not full: nothing is left
+  }
 
   // ---- running list from a previous panel
   if (a.merge) {
     int mine = 0;
-    for (int r = tid; r < k; r += TK_THREADS) mine += a.idx[q * k + r] >= 0;
+    for (int r = tid; r < k; r += TK_THREADS) mine += oidx[r] >= 0;
     const int incl = block_incl_scan(mine, stmp, lane, wave);
     int pos = incl - mine;
     for (int r = tid; r < k; r += TK_THREADS) {
-      const int64_t id = a.idx[q * k + r];
-      if (id >= 0) run[cur][pos++] = make_key(a.val[q * k + r], (uint32_t)id);
+      const int64_t id = oidx[r];
+      if (id >= 0) run[cur][pos++] = make_key(oval[r], (uint32_t)id);
     }
     if (tid == TK_THREADS - 1) s_cnt = incl;
     __syncthreads();
@@ -102,8 +114,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkArgs a) {
           const int64_t id = a.idx_lists[off];
           if (id >= 0) { key[it] = make_key(a.scores[off], (uint32_t)id); ++nvalid; }
         } else {
-          key[it] = make_key(a.scores[q * a.ld + c], (uint32_t)(a.col_offset + c));
-          ++nvalid;
+          const uint64_t kk = make_key(a.scores[q * a.ld + c], (uint32_t)(a.col_offset + c));
+          if (kk < upper) { key[it] = kk; ++nvalid; }
         }
       }
     }
@@ -178,11 +190,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(TopkArgs a) {
   for (int r = tid; r < k; r += TK_THREADS) {
     if (r < run_count) {  // run_count may exceed k only with duplicate inputs; the sort keeps the best first
       const uint64_t kk = run[cur][r];
-      a.idx[q * k + r] = (int64_t)(uint32_t)(~(uint32_t)(kk & 0xffffffffull));
-      a.val[q * k + r] = unmono_f32((uint32_t)(kk >> 32));
+      oidx[r] = (int64_t)(uint32_t)(~(uint32_t)(kk & 0xffffffffull));
+      oval[r] = unmono_f32((uint32_t)(kk >> 32));
     } else {
-      a.idx[q * k + r] = -1;
-      a.val[q * k + r] = -INFINITY;
+      oidx[r] = -1;
+      oval[r] = -INFINITY;
     }
   }
 }
@@ -200,14 +212,25 @@ static int launch_topk_impl(pvs_ctx* ctx, const TopkArgs& a) {
 
 int launch_topk(pvs_ctx* ctx, const float* scores, int64_t nq, int64_t ncols, int64_t ld, int k, int64_t col_offset,
                 int merge, int64_t* d_idx, float* d_val) {
-  TopkArgs a{scores, nullptr, nq, ncols, ld, k, col_offset, merge, 0, d_idx, d_val};
-  return launch_topk_impl(ctx, a);
+  if (k <= TK_KMAX) {
+    TopkArgs a{scores, nullptr, nq, ncols, ld, k, col_offset, merge, 0, d_idx, d_val, k, 0};
+    return launch_topk_impl(ctx, a);
+  }
+  // deep ranking (e.g. top_k_map(k=None) = full argsort): pages of TK_KMAX, each page selects the best keys that
+  // are strictly worse than the previous page's last key.  Needs the whole score row in this panel.
+  if (merge) PVS_FAIL(PVS_ERR_UNSUPPORTED, "top-k deeper than %d cannot merge across panels", TK_KMAX);
+  for (int off = 0; off < k; off += TK_KMAX) {
+    TopkArgs a{scores, nullptr, nq, ncols, ld, std::min(TK_KMAX, k - off), col_offset, 0, 0, d_idx, d_val, k, off};
+    PVS_TRY(launch_topk_impl(ctx, a));
+  }
+  return PVS_OK;
 }
 
 int launch_topk_merge(pvs_ctx* ctx, const int64_t* idx_lists, const float* val_lists, int n_lists, int64_t nq, int k,
                       int64_t* d_idx, float* d_val) {
   if (n_lists < 1) PVS_FAIL(PVS_ERR_INVALID, "top-k merge: n_lists must be >= 1");
-  TopkArgs a{val_lists, idx_lists, nq, (int64_t)n_lists * k, 0, k, 0, 0, n_lists, d_idx, d_val};
+  if (k > TK_KMAX) PVS_FAIL(PVS_ERR_UNSUPPORTED, "top-k merge: k must be <= %d", TK_KMAX);
+  TopkArgs a{val_lists, idx_lists, nq, (int64_t)n_lists * k, 0, k, 0, 0, n_lists, d_idx, d_val, k, 0};
   return launch_topk_impl(ctx, a);
 }
 

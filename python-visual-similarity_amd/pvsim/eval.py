@@ -16,7 +16,6 @@ from .engine import default_context
 
 __all__ = ["retrieve_top_k_similar", "top_k_map", "top_k_accuracy"]
 
-_K_DEVICE_MAX = 1024
 
 
 def _first_rows(encoder, queries) -> np.ndarray:
@@ -42,8 +41,6 @@ def _rank(query_vecs: np.ndarray, all_vectors: np.ndarray, k: int | None, ctx=No
     if query_vecs.shape[-1] <= 1 or all_vectors.shape[-1] <= 1:
         raise ValueError(f"Cosine similarity requires at least 2 features. Got {query_vecs.shape[-1]} features "
                          f"for x and {all_vectors.shape[-1]} features for y.")
-    if kk > _K_DEVICE_MAX:
-        raise NotImplementedError(f"ranking depth {kk} exceeds the device top-k limit ({_K_DEVICE_MAX})")
     q32 = np.ascontiguousarray(query_vecs, dtype=np.float32)
     d32 = np.ascontiguousarray(all_vectors, dtype=np.float32)
     return ctx.cosine_topk(q32, d32, kk)

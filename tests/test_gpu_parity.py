@@ -205,6 +205,16 @@ def test_topk_vs_stable_argsort(gpu_ctx, nq, N, k):
     _check_topk(gpu_ctx, q, db, k)
 
 
+def test_deep_ranking_pages(gpu_ctx):
+    """k > 1024 (top_k_map(k=None) is a full argsort): paged select, equal to a stable argsort of the scores."""
+    rng = np.random.default_rng(8)
+    db = rng.normal(size=(5000, 32)).astype(np.float32)
+    db[100] = db[7]; db[4000] = db[7]                  # ties across page boundaries are broken by index
+    q = rng.normal(size=(3, 32)).astype(np.float32)
+    for k in (1025, 2500, 5000):
+        _check_topk(gpu_ctx, q, db, k)
+
+
 def test_topk_all_ties_and_self(gpu_ctx):
     db = np.ones((500, 16), np.float32)              # every score identical: pure index order
     idx, _ = gpu_ctx.cosine_topk(db[:3], db, 9)
@@ -302,3 +312,43 @@ def test_config2_sized_properties(gpu_ctx, tables):
     assert np.abs(s - s.T).max() < 1e-6
     ridx, _ = orc.topk(orc.cosine_similarity(v[sub], v), 5)
     assert np.array_equal(idx[sub], ridx)
+
+
+# ======================================================================================= multi-GPU decomposition
+@pytest.mark.parametrize("world,n_total", [(3, 1000), (8, 8189 // 4), (2, 257)])
+def test_sharded_decomposition_on_one_gpu(gpu_ctx, world, n_total):
+    """The N-rank decomposition of bench.py / pvsim.distributed run rank by rank on ONE GPU (the all-gather is
+    emulated by laying the padded blocks out as all_gather_into_tensor would): uneven last block, true global
+    indices, running top-k merge across blocks -- must equal the single-GPU answer exactly."""
+    import torch
+    from pvsim import distributed as pd
+    rng = np.random.default_rng(world * 100 + n_total)
+    L, k = 512, 6
+    enc = rng.normal(size=(n_total, L)).astype(np.float32)
+    enc[n_total // 2] = enc[3]                                   # a tie that straddles blocks
+    ref_idx, ref_val = gpu_ctx.cosine_topk(enc, enc, k)
+    dev = torch.device("cuda", 0)
+    _, _, block = pd.shard_range(n_total, world, 0)
+    enc_all = torch.zeros((world * block, L), dtype=torch.float32, device=dev)
+    inv_all = torch.ones((world * block,), dtype=torch.float32, device=dev)
+    for r in range(world):
+        lo, hi, _ = pd.shard_range(n_total, world, r)
+        enc_all[r * block: r * block + hi - lo] = torch.from_numpy(enc[lo:hi]).to(dev)
+    torch.cuda.synchronize()
+    gpu_ctx.row_inv_norms_dev(enc_all.data_ptr(), world * block, L, inv_all.data_ptr())
+    gpu_ctx.sync()
+    score = pd.device_score_block(gpu_ctx)
+    got_idx, got_val = [], []
+    for r in range(world):
+        lo, hi, _ = pd.shard_range(n_total, world, r)
+        idx = torch.full((block, k), -1, dtype=torch.int64, device=dev)
+        val = torch.full((block, k), float("-inf"), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        n_loc = pd.retrieve_sharded(enc_all[r * block:], inv_all[r * block:], enc_all, inv_all, n_total, r, world, k,
+                                    score, idx, val)
+        gpu_ctx.sync()
+        assert n_loc == hi - lo
+        got_idx.append(idx[:n_loc].cpu().numpy())
+        got_val.append(val[:n_loc].cpu().numpy())
+    assert np.array_equal(np.concatenate(got_idx), ref_idx)
+    assert np.array_equal(np.concatenate(got_val), ref_val)
