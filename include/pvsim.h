@@ -146,6 +146,15 @@ int pvs_topk_dev(pvs_ctx* ctx, const float* d_scores, int64_t nq, int64_t ncols,
 int pvs_cosine_topk_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L,
                         const float* d_inv_q, const float* d_inv_db, int k, int64_t col_offset, int merge,
                         int64_t* d_idx, float* d_val);
+/* fp16 operands (BASELINE configs[4]: the 1M x 1M similarity on fp16 encodings): fp32 rows are converted once
+ * (round-to-nearest-even; keep the intra-normalised VLAD values and pass the fp32 1/||row|| factors, do not
+ * pre-divide -- that would push elements into fp16 subnormals), then v_mfma_f32_32x32x16_f16 with fp32 accumulate. */
+int pvs_f32_to_f16_dev(pvs_ctx* ctx, const float* d_src, int64_t n, void* d_dst_f16);
+int pvs_cosine_f16_dev(pvs_ctx* ctx, const void* d_A16, int64_t M, const void* d_B16, int64_t N, int64_t L,
+                       const float* d_inv_a, const float* d_inv_b, float* d_out, int64_t ldo);
+int pvs_cosine_topk_f16_dev(pvs_ctx* ctx, const void* d_Q16, int64_t nq, const void* d_DB16, int64_t N, int64_t L,
+                            const float* d_inv_q, const float* d_inv_db, int k, int64_t col_offset, int merge,
+                            int64_t* d_idx, float* d_val);
 int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L, int k,
                     int64_t* out_idx, float* out_val);
 /* merges per-rank top-k lists (multi-GPU: each rank scored its own DB shard): lists [n_lists][nq][k]. */

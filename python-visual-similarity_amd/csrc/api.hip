@@ -585,9 +585,10 @@ PVS_EXPORT int pvs_topk_merge_dev(pvs_ctx* ctx, const int64_t* d_idx_lists, cons
   return launch_topk_merge(ctx, d_idx_lists, d_val_lists, n_lists, nq, k, d_idx, d_val);
 }
 
-PVS_EXPORT int pvs_cosine_topk_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L,
-                                   const float* d_inv_q, const float* d_inv_db, int k, int64_t col_offset, int merge,
-                                   int64_t* d_idx, float* d_val) {
+// GEMM panel + select, tiled over queries and database columns; `f16` selects the fp16-operand GEMM
+static int cosine_topk_impl(pvs_ctx* ctx, const void* d_Q, int64_t nq, const void* d_DB, int64_t N, int64_t L, bool f16,
+                            const float* d_inv_q, const float* d_inv_db, int k, int64_t col_offset, int merge,
+                            int64_t* d_idx, float* d_val) {
   PVS_NEED(ctx, "ctx");
   if (nq <= 0) return PVS_OK;
   PVS_NEED(d_Q, "Q");
@@ -604,19 +605,60 @@ PVS_EXPORT int pvs_cosine_topk_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, c
   const int64_t NC = deep ? N : std::min<int64_t>(N, 32768);
   const int64_t QT = deep ? std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 28) / N))
                           : std::min<int64_t>(nq, 8192);
+  const size_t esz = f16 ? 2 : 4;
+  const char* q = static_cast<const char*>(d_Q);
+  const char* db = static_cast<const char*>(d_DB);
   float* panel = nullptr;
   PVS_TRY(ws_reserve(ctx, 2, (size_t)QT * NC * sizeof(float), reinterpret_cast<void**>(&panel)));
   for (int64_t q0 = 0; q0 < nq; q0 += QT) {
     const int64_t qn = std::min(QT, nq - q0);
     for (int64_t c0 = 0; c0 < N; c0 += NC) {
       const int64_t cn = std::min(NC, N - c0);
-      PVS_TRY(launch_cosine_f32(ctx, d_Q + q0 * L, qn, d_DB + c0 * L, cn, L, d_inv_q ? d_inv_q + q0 : nullptr,
-                                d_inv_db ? d_inv_db + c0 : nullptr, panel, cn));
+      const float* iq = d_inv_q ? d_inv_q + q0 : nullptr;
+      const float* idb = d_inv_db ? d_inv_db + c0 : nullptr;
+      if (f16)
+        PVS_TRY(launch_cosine_f16(ctx, q + (size_t)q0 * L * esz, qn, db + (size_t)c0 * L * esz, cn, L, iq, idb, panel, cn));
+      else
+        PVS_TRY(launch_cosine_f32(ctx, reinterpret_cast<const float*>(q) + q0 * L, qn,
+                                  reinterpret_cast<const float*>(db) + c0 * L, cn, L, iq, idb, panel, cn));
       PVS_TRY(launch_topk(ctx, panel, qn, cn, cn, k, col_offset + c0, (merge || c0 > 0) ? 1 : 0, d_idx + q0 * k,
                           d_val + q0 * k));
     }
   }
   return PVS_OK;
+}
+
+PVS_EXPORT int pvs_cosine_topk_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L,
+                                   const float* d_inv_q, const float* d_inv_db, int k, int64_t col_offset, int merge,
+                                   int64_t* d_idx, float* d_val) {
+  return cosine_topk_impl(ctx, d_Q, nq, d_DB, N, L, false, d_inv_q, d_inv_db, k, col_offset, merge, d_idx, d_val);
+}
+
+PVS_EXPORT int pvs_cosine_topk_f16_dev(pvs_ctx* ctx, const void* d_Q16, int64_t nq, const void* d_DB16, int64_t N,
+                                       int64_t L, const float* d_inv_q, const float* d_inv_db, int k, int64_t col_offset,
+                                       int merge, int64_t* d_idx, float* d_val) {
+  return cosine_topk_impl(ctx, d_Q16, nq, d_DB16, N, L, true, d_inv_q, d_inv_db, k, col_offset, merge, d_idx, d_val);
+}
+
+PVS_EXPORT int pvs_f32_to_f16_dev(pvs_ctx* ctx, const float* d_src, int64_t n, void* d_dst) {
+  PVS_NEED(ctx, "ctx");
+  if (n <= 0) return PVS_OK;
+  PVS_NEED(d_src, "src");
+  PVS_NEED(d_dst, "dst");
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_f32_to_f16(ctx, d_src, n, d_dst);
+}
+
+PVS_EXPORT int pvs_cosine_f16_dev(pvs_ctx* ctx, const void* d_A16, int64_t M, const void* d_B16, int64_t N, int64_t L,
+                                  const float* d_inv_a, const float* d_inv_b, float* d_out, int64_t ldo) {
+  PVS_NEED(ctx, "ctx");
+  if (M <= 0 || N <= 0) return PVS_OK;
+  PVS_NEED(d_A16, "A");
+  PVS_NEED(d_B16, "B");
+  PVS_NEED(d_out, "out");
+  if (ldo < N) PVS_FAIL(PVS_ERR_INVALID, "cosine: ldo (%lld) < N (%lld)", (long long)ldo, (long long)N);
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_cosine_f16(ctx, d_A16, M, d_B16, N, L, d_inv_a, d_inv_b, d_out, ldo);
 }
 
 PVS_EXPORT int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L, int k,

@@ -10,7 +10,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "../gemm_f32.hpp"
+#include "../gemm_mfma.hpp"
 
 using namespace pvs;
 
@@ -46,6 +46,21 @@ __global__ void ref_samples(const float* x, const float* inv, int64_t L, int64_t
   if (lane == 0) out[s] = acc * (double)inv[sm[s]] * (double)inv[sn[s]];
 }
 
+__global__ void to_half(const float* x, _Float16* y, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (_Float16)x[i];
+}
+__global__ void ref_samples_h(const _Float16* x, const float* inv, int64_t L, int64_t ld, const int* sm, const int* sn,
+                              int ns, double* out) {
+  const int s = blockIdx.x;
+  if (s >= ns) return;
+  const int lane = threadIdx.x;
+  double acc = 0.0;
+  for (int64_t i = lane; i < L; i += 64) acc += (double)(float)x[(int64_t)sm[s] * ld + i] * (double)(float)x[(int64_t)sn[s] * ld + i];
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if (lane == 0) out[s] = acc * (double)inv[sm[s]] * (double)inv[sn[s]];
+}
+
 __device__ __attribute__((aligned(16))) float d_zero16[4] = {0, 0, 0, 0};
 static int64_t g_ld = 0;  // operand row stride (floats)
 
@@ -68,10 +83,11 @@ static std::vector<GemmTile> tile_list(int tm_n, int tn_n, bool symm) {
 }
 
 // TAILK > 1: the tiles of the last partial round (slots = 512) go through the split-K tail
-template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, bool STAMP = false>
-static void run(const char* name, const float* A, const float* inv, int64_t N, int64_t L, float* out, int ns,
+template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, bool STAMP = false, bool F16 = false,
+          bool TWO = true, bool ILV = false>
+static void run(const char* name, const void* A, const float* inv, int64_t N, int64_t L, float* out, int ns,
                 const double* ref_h, const int* sm_h, const int* sn_h, int tailk) {
-  using Cfg = GemmCfg<BM, BN, WM, WN, STAGES>;
+  using Cfg = GemmCfg<BM, BN, WM, WN, STAGES, F16>;
   GemmArgs g{};
   g.A = A; g.B = A; g.M = N; g.N = N; g.L = L; g.lda = g_ld; g.ldb = g_ld; g.inva = inv; g.invb = inv; g.out = out;
   g.ldo = N; g.splitk = 1;
@@ -80,14 +96,14 @@ static void run(const char* name, const float* A, const float* inv, int64_t N, i
   GemmTile* d_t; CK(hipMalloc(&d_t, t.size() * sizeof(GemmTile)));
   CK(hipMemcpy(d_t, t.data(), t.size() * sizeof(GemmTile), hipMemcpyHostToDevice));
   g.tiles = d_t;
-  const int slots = 512, total = (int)t.size();
+  const int slots = 256 * (OCC * 256 / Cfg::THREADS), total = (int)t.size();
   int n_main = total, n_tail = 0;
   if (tailk > 1 && total > slots && total % slots) { n_tail = total % slots; n_main = total - n_tail; }
   float* part = nullptr;
   if (n_tail) CK(hipMalloc(&part, (size_t)n_tail * tailk * BM * BN * 4));
-  auto kf = gemm_f32_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_FULL, STAMP>;
-  auto kp = gemm_f32_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_PARTIAL>;
-  auto kr = gemm_f32_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_REDUCE>;
+  auto kf = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_FULL, STAMP, F16, TWO, ILV>;
+  auto kp = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_PARTIAL, false, F16, TWO, ILV>;
+  auto kr = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_REDUCE, false, F16, TWO, ILV>;
   for (const void* k : {(const void*)kf, (const void*)kp, (const void*)kr})
     CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
   if (STAMP) CK(hipMalloc(&g.stamps, (size_t)n_main * 64));
@@ -126,7 +142,7 @@ static void run(const char* name, const float* A, const float* inv, int64_t N, i
   const double flop_alg = 2.0 * (double)N * (double)N * (double)L, flop_exec = 2.0 * BM * BN * (double)L * total;
   printf("%-26s tiles %5d (+%d x splitK %d)  avg %8.3f ms  best %8.3f  executed %7.2f TF/s  algorithmic %7.2f TF/s  maxerr %.2e %s\n",
          name, n_main, n_tail, n_tail ? tailk : 1, sum / 3, best, flop_exec / (sum / 3 * 1e-3) / 1e12,
-         flop_alg / (sum / 3 * 1e-3) / 1e12, maxerr, maxerr < 2e-6 ? "ok" : "FAIL");
+         flop_alg / (sum / 3 * 1e-3) / 1e12, maxerr, maxerr < (F16 ? 2e-5 : 2e-6) ? "ok" : "FAIL");
   if (STAMP) {
     std::vector<unsigned long long> h((size_t)n_main * 8);
     CK(hipMemcpy(h.data(), g.stamps, (size_t)n_main * 64, hipMemcpyDeviceToHost));
@@ -137,9 +153,9 @@ static void run(const char* name, const float* A, const float* inv, int64_t N, i
       for (int q = 0; q < 4; ++q) seg[q] += (double)h[8 * b + 4 + q];
     }
     std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
-    const double nkt = (double)n_main * (double)((L + 31) / 32);
-    printf("   [stamped build] clock %.3f GHz; block loop %.1f cyc per k-tile (MFMA floor 8192); per k-tile: vmcnt %.0f barrier %.0f"
-           " issue %.0f reads+MFMA %.0f\n", clk[clk.size() / 2], cyc[cyc.size() / 2] / (double)((L + 31) / 32), seg[0] / nkt,
+    const double nkt = (double)n_main * (double)((L + Cfg::BK - 1) / Cfg::BK);
+    printf("   [stamped build] clock %.3f GHz; block loop %.1f cyc per k-tile; per k-tile: vmcnt %.0f barrier %.0f"
+           " issue %.0f reads+MFMA %.0f\n", clk[clk.size() / 2], cyc[cyc.size() / 2] / (double)((L + Cfg::BK - 1) / Cfg::BK), seg[0] / nkt,
            seg[1] / nkt, seg[2] / nkt, seg[3] / nkt);
     CK(hipFree(g.stamps));
   }
@@ -167,11 +183,26 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(ref.data(), d_ref, ns * 8, hipMemcpyDeviceToHost));
   printf("N=%lld L=%lld ld=%lld\n", (long long)N, (long long)L, (long long)g_ld);
 #define RUN(BM, BN, WM, WN, ST, SY, OCC, TK) run<BM, BN, WM, WN, ST, SY, OCC>(#BM "x" #BN " w" #WM "x" #WN " st" #ST " symm" #SY, A, inv, N, L, out, ns, ref.data(), sm.data(), sn.data(), TK)
-  RUN(128, 128, 2, 2, 2, false, 2, 1);
-  run<128, 128, 2, 2, 2, false, 2, true>("128x128 stamped", A, inv, N, L, out, ns, ref.data(), sm.data(), sn.data(), 1);
-  RUN(128, 128, 2, 2, 2, true, 2, 1);
-  RUN(128, 128, 2, 2, 2, true, 2, 8);
-  RUN(128, 128, 2, 2, 2, true, 2, 16);
-  RUN(128, 128, 2, 2, 3, false, 2, 1);
+#define RUNH(BM, BN, WM, WN, ST, SY, OCC, ILV, TK) run<BM, BN, WM, WN, ST, SY, OCC, false, true, false, ILV>("f16 " #BM "x" #BN " w" #WM "x" #WN " st" #ST " symm" #SY " ilv" #ILV, A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), TK)
+  const int which = argc > 4 ? atoi(argv[4]) : 0;
+  if (which == 0 || which == 1) {
+    RUN(128, 128, 2, 2, 2, false, 2, 1);
+    run<128, 128, 2, 2, 2, false, 2, true>("128x128 stamped", A, inv, N, L, out, ns, ref.data(), sm.data(), sn.data(), 1);
+    RUN(128, 128, 2, 2, 2, true, 2, 16);
+  }
+  if (which == 0 || which == 2) {
+    _Float16* A16; CK(hipMalloc(&A16, (size_t)N * g_ld * 2));
+    hipLaunchKernelGGL(to_half, dim3((unsigned)(((int64_t)N * g_ld + 255) / 256)), dim3(256), 0, 0, A, A16, N * g_ld);
+    hipLaunchKernelGGL(ref_samples_h, dim3(ns), dim3(64), 0, 0, A16, inv, L, g_ld, d_sm, d_sn, ns, d_ref);
+    std::vector<double> refh(ns);
+    CK(hipMemcpy(refh.data(), d_ref, ns * 8, hipMemcpyDeviceToHost));
+    RUNH(256, 256, 2, 4, 2, false, 2, false, 1);
+    RUNH(256, 256, 2, 4, 2, false, 2, true, 1);
+    run<256, 256, 2, 4, 2, false, 2, true, true, false, false>("f16 256x256 stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
+    RUNH(128, 128, 2, 2, 2, false, 2, false, 1);
+    RUNH(128, 128, 2, 2, 2, false, 2, true, 1);
+    RUNH(256, 256, 2, 4, 2, true, 2, false, 8);
+    RUNH(256, 256, 2, 4, 2, true, 2, true, 8);
+  }
   return 0;
 }

@@ -125,6 +125,9 @@ int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_de
 int launch_row_inv_norms(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L, float* d_inv);
 int launch_cosine_f32(pvs_ctx* ctx, const float* A, int64_t M, const float* B, int64_t N, int64_t L,
                       const float* inva, const float* invb, float* out, int64_t ldo);
+int launch_cosine_f16(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
+                      const float* invb, float* out, int64_t ldo);
+int launch_f32_to_f16(pvs_ctx* ctx, const float* src, int64_t n, void* dst);
 int launch_cosine_f64(pvs_ctx* ctx, const double* A, int64_t M, const double* B, int64_t N, int64_t L, double* out);
 int launch_topk(pvs_ctx* ctx, const float* scores, int64_t nq, int64_t ncols, int64_t ld, int k,
                 int64_t col_offset, int merge, int64_t* d_idx, float* d_val);

@@ -10,9 +10,10 @@
 // buffered; LDS image XOR-swizzled on the SOURCE address + matching XOR on the ds_read_b128 (conflict
 // free); block -> tile map is XCD-aware so the 64 tiles resident on one XCD share 8 A and 8 B panels.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.hpp"
-#include "gemm_f32.hpp"
+#include "gemm_mfma.hpp"
 
 namespace pvs {
 
@@ -51,11 +52,11 @@ int launch_row_inv_norms(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L
 }
 
 // ------------------------------------------------------------------------------------- K6 fp32 MFMA
-// Kernel: gemm_f32.hpp (128x128 tile, 4 waves, 2 stages, 2 workgroups per CU).  The host builds the tile list:
+// Kernel: gemm_mfma.hpp (128x128 tile, 4 waves, 2 stages, 2 workgroups per CU).  The host builds the tile list:
 // 8x8 super-tiles for L2 panel sharing, upper triangle only when A == B (SYMM), and -- when the last round of
 // workgroups would be mostly empty -- hands the remaining tiles to a deterministic split-K tail.
-using GemmMain = GemmCfg<128, 128, 2, 2, 2>;
-constexpr int GEMM_BLOCKS_PER_CU = 2;
+using GemmMain = GemmCfg<128, 128, 2, 2, 2, false>;   // exact fp32: 2 workgroups per CU
+using GemmHalf = GemmCfg<256, 256, 2, 4, 2, true>;    // fp16 operands: 1 workgroup (8 waves) per CU
 
 struct GemmPlanKey {
   int tiles_m = -1, tiles_n = -1, symm = -1, slots = -1;
@@ -69,12 +70,12 @@ struct GemmPlan {
   GemmTile* d_tiles = nullptr;
   size_t cap = 0;
 };
-static GemmPlan g_plan;  // one cached plan per process (single context per process is the norm)
+static GemmPlan g_plan[2];  // [0] fp32 kernel, [1] fp16 kernel: one cached plan each per process
 
-static int build_plan(pvs_ctx* ctx, int tiles_m, int tiles_n, bool symm, GemmPlan** out) {
-  const int slots = ctx->num_cu * GEMM_BLOCKS_PER_CU;
+static int build_plan(pvs_ctx* ctx, int which, int tiles_m, int tiles_n, bool symm, int slots, GemmPlan** out) {
+  GemmPlan& P = g_plan[which];
   const GemmPlanKey key{tiles_m, tiles_n, symm ? 1 : 0, slots};
-  if (!(g_plan.key == key)) {
+  if (!(P.key == key)) {
     std::vector<GemmTile> t;
     if (symm) {
       const int TS = (tiles_m + 7) / 8;
@@ -93,59 +94,124 @@ static int build_plan(pvs_ctx* ctx, int tiles_m, int tiles_n, bool symm, GemmPla
     }
     const int total = (int)t.size();
     const int rounds = total / slots, rem = total % slots;
-    g_plan.n_main = total;
-    g_plan.n_tail = 0;
-    g_plan.splitk = 1;
+    P.n_main = total;
+    P.n_tail = 0;
+    P.splitk = 1;
     if (rounds >= 1 && rem > 0 && rem <= slots / 2) {  // the last round would leave >= half the chip idle
       int s = 2;
       while (s * 2 <= 16 && rem * s * 2 <= slots) s *= 2;
-      g_plan.n_main = total - rem;
-      g_plan.n_tail = rem;
-      g_plan.splitk = s;
+      P.n_main = total - rem;
+      P.n_tail = rem;
+      P.splitk = s;
     }
-    if (g_plan.cap < t.size()) {
+    if (P.cap < t.size()) {
       PVS_HIP(hipStreamSynchronize(ctx->stream));
-      if (g_plan.d_tiles) PVS_HIP(hipFree(g_plan.d_tiles));
-      g_plan.cap = t.size() + t.size() / 4 + 64;
-      PVS_HIP(hipMalloc(reinterpret_cast<void**>(&g_plan.d_tiles), g_plan.cap * sizeof(GemmTile)));
+      if (P.d_tiles) PVS_HIP(hipFree(P.d_tiles));
+      P.cap = t.size() + t.size() / 4 + 64;
+      PVS_HIP(hipMalloc(reinterpret_cast<void**>(&P.d_tiles), P.cap * sizeof(GemmTile)));
     }
-    PVS_HIP(hipMemcpyAsync(g_plan.d_tiles, t.data(), t.size() * sizeof(GemmTile), hipMemcpyHostToDevice, ctx->stream));
+    PVS_HIP(hipMemcpyAsync(P.d_tiles, t.data(), t.size() * sizeof(GemmTile), hipMemcpyHostToDevice, ctx->stream));
     PVS_HIP(hipStreamSynchronize(ctx->stream));  // `t` is pageable host memory going out of scope
-    g_plan.key = key;
+    P.key = key;
   }
-  *out = &g_plan;
+  *out = &P;
   return PVS_OK;
 }
 
-template <bool SYMM>
+template <bool SYMM, bool F16>
 static int launch_gemm_mfma(pvs_ctx* ctx, GemmArgs g, const GemmPlan& plan) {
-  auto kfull = gemm_f32_kernel<128, 128, 2, 2, 2, SYMM, 2, GEMM_MODE_FULL>;
-  auto kpart = gemm_f32_kernel<128, 128, 2, 2, 2, SYMM, 2, GEMM_MODE_PARTIAL>;
-  auto kred = gemm_f32_kernel<128, 128, 2, 2, 2, SYMM, 2, GEMM_MODE_REDUCE>;
+  using Cfg = std::conditional_t<F16, GemmHalf, GemmMain>;
+  constexpr int BM = F16 ? 256 : 128, WM = 2, WN = F16 ? 4 : 2;
+  // fp16: single-level accumulation (input rounding dominates); LDS-DMA interleaved into the MFMA phase pays only
+  // in the general (non-symmetric) order (measured 3.62 vs 3.91 ms; symmetric 2.19 vs 1.98 ms)
+  constexpr bool TWO = !F16, ILV = F16 && !SYMM;
+  auto kfull = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_FULL, false, F16, TWO, ILV>;
+  auto kpart = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_PARTIAL, false, F16, TWO, ILV>;
+  auto kred = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_REDUCE, false, F16, TWO, ILV>;
   static bool attr_set = false;
   if (!attr_set) {
     for (const void* k : {reinterpret_cast<const void*>(kfull), reinterpret_cast<const void*>(kpart),
                           reinterpret_cast<const void*>(kred)})
-      PVS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, GemmMain::LDS_BYTES));
+      PVS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     attr_set = true;
   }
   if (plan.n_main > 0) {
     g.tile_base = 0;
-    hipLaunchKernelGGL(kfull, dim3((unsigned)plan.n_main), dim3(GemmMain::THREADS), GemmMain::LDS_BYTES, ctx->stream, g);
+    hipLaunchKernelGGL(kfull, dim3((unsigned)plan.n_main), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
   }
   if (plan.n_tail > 0) {
     float* part = nullptr;
-    PVS_TRY(ws_reserve(ctx, 4, (size_t)plan.n_tail * plan.splitk * 128 * 128 * sizeof(float),
+    PVS_TRY(ws_reserve(ctx, 4, (size_t)plan.n_tail * plan.splitk * BM * BM * sizeof(float),
                        reinterpret_cast<void**>(&part)));
     g.tile_base = plan.n_main;
     g.splitk = plan.splitk;
     g.partial = part;
-    hipLaunchKernelGGL(kpart, dim3((unsigned)(plan.n_tail * plan.splitk)), dim3(GemmMain::THREADS), GemmMain::LDS_BYTES,
+    hipLaunchKernelGGL(kpart, dim3((unsigned)(plan.n_tail * plan.splitk)), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
                        ctx->stream, g);
-    hipLaunchKernelGGL(kred, dim3((unsigned)plan.n_tail), dim3(GemmMain::THREADS), GemmMain::LDS_BYTES, ctx->stream, g);
+    hipLaunchKernelGGL(kred, dim3((unsigned)plan.n_tail), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
   }
   PVS_HIP(hipGetLastError());
   return PVS_OK;
+}
+
+// shared front end of the two MFMA paths
+template <bool F16>
+static int cosine_mfma(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
+                       const float* invb, float* out, int64_t ldo) {
+  constexpr int BT = F16 ? 256 : 128;
+  const int tiles_m = (int)((M + BT - 1) / BT), tiles_n = (int)((N + BT - 1) / BT);
+  if ((int64_t)tiles_m * tiles_n > 0x3fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "cosine: too many tiles for one launch");
+  // self-similarity: same operand, same norms -> only the upper triangle is computed, the rest mirrored
+  const bool symm = (A == B) && (M == N) && (inva == invb);
+  GemmPlan* plan = nullptr;
+  PVS_TRY(build_plan(ctx, F16 ? 1 : 0, tiles_m, tiles_n, symm, ctx->num_cu * (F16 ? 1 : 2), &plan));
+  GemmArgs g{};
+  g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = L; g.ldb = L; g.inva = inva; g.invb = invb;
+  g.out = out; g.ldo = ldo; g.tiles = plan->d_tiles; g.splitk = 1;
+  PVS_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(const_cast<float**>(&g.zero16)), HIP_SYMBOL(g_zero16)));
+  if (symm) return launch_gemm_mfma<true, F16>(ctx, g, *plan);
+  return launch_gemm_mfma<false, F16>(ctx, g, *plan);
+}
+
+// ------------------------------------------------------------------------------------- fp32 -> fp16 encodings
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float4* __restrict__ src, int64_t n4, uint2* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = src[i];
+    union { _Float16 h[4]; uint2 u; } o;
+    o.h[0] = (_Float16)v.x; o.h[1] = (_Float16)v.y; o.h[2] = (_Float16)v.z; o.h[3] = (_Float16)v.w;  // round-to-nearest-even
+    dst[i] = o.u;
+  }
+}
+__global__ void f32_to_f16_tail_kernel(const float* __restrict__ src, int64_t start, int64_t n, _Float16* __restrict__ dst) {
+  const int64_t i = start + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (_Float16)src[i];
+}
+
+int launch_f32_to_f16(pvs_ctx* ctx, const float* src, int64_t n, void* dst) {
+  if (n <= 0) return PVS_OK;
+  ScopedTimer tm(ctx, T_MISC);
+  const bool vec = reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 8 == 0;
+  const int64_t n4 = vec ? n / 4 : 0;
+  if (n4 > 0) {
+    const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)ctx->num_cu * 16);
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(src), n4,
+                       reinterpret_cast<uint2*>(dst));
+  }
+  if (n4 * 4 < n)
+    hipLaunchKernelGGL(f32_to_f16_tail_kernel, dim3((unsigned)((n - n4 * 4 + 255) / 256)), dim3(256), 0, ctx->stream, src,
+                       n4 * 4, n, reinterpret_cast<_Float16*>(dst));
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+int launch_cosine_f16(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
+                      const float* invb, float* out, int64_t ldo) {
+  if (M <= 0 || N <= 0) return PVS_OK;
+  if (L <= 0 || L % 8 != 0 || reinterpret_cast<uintptr_t>(A) % 16 || reinterpret_cast<uintptr_t>(B) % 16)
+    PVS_FAIL(PVS_ERR_UNSUPPORTED, "fp16 cosine needs 16-B aligned rows (L %% 8 == 0), got L = %lld", (long long)L);
+  if (L > (int64_t)16 * 1024 * 1024) PVS_FAIL(PVS_ERR_UNSUPPORTED, "fp16 cosine: L too large");
+  ScopedTimer tm(ctx, T_GEMM);
+  return cosine_mfma<true>(ctx, A, M, B, N, L, inva, invb, out, ldo);
 }
 
 // ------------------------------------------------------------------------------------- generic tiled fallback
@@ -212,18 +278,7 @@ int launch_cosine_f32(pvs_ctx* ctx, const float* A, int64_t M, const float* B, i
                     (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (L <= (int64_t)8 * 1024 * 1024);
   ScopedTimer tm(ctx, T_GEMM);
   if (fast) {
-    const int tiles_m = (int)((M + 127) / 128), tiles_n = (int)((N + 127) / 128);
-    if ((int64_t)tiles_m * tiles_n > 0x3fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "cosine: too many tiles for one launch");
-    // self-similarity: same operand, same norms -> only the upper triangle is computed, the rest mirrored
-    const bool symm = (A == B) && (M == N) && (inva == invb);
-    GemmPlan* plan = nullptr;
-    PVS_TRY(build_plan(ctx, tiles_m, tiles_n, symm, &plan));
-    GemmArgs g{};
-    g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = L; g.ldb = L; g.inva = inva; g.invb = invb;
-    g.out = out; g.ldo = ldo; g.tiles = plan->d_tiles; g.splitk = 1;
-    PVS_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(const_cast<float**>(&g.zero16)), HIP_SYMBOL(g_zero16)));
-    if (symm) PVS_TRY(launch_gemm_mfma<true>(ctx, g, *plan));
-    else PVS_TRY(launch_gemm_mfma<false>(ctx, g, *plan));
+    PVS_TRY(cosine_mfma<false>(ctx, A, M, B, N, L, inva, invb, out, ldo));
   } else {
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
     hipLaunchKernelGGL(cosine_gemm_generic_kernel<float>, grid, dim3(256), 0, ctx->stream, A, M, B, N, L, inva, invb,

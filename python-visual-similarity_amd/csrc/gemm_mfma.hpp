@@ -1,9 +1,13 @@
-// Exact-fp32 MFMA "NT" GEMM for the cosine step:  out[m][n] = (A_m . B_n) * (inva[m] * invb[n]),
+// MFMA "NT" GEMM for the cosine step:  out[m][n] = (A_m . B_n) * (inva[m] * invb[n])  (fp32 out),
 // A [M][lda], B [N][ldb] both K-major (row = one encoding).  Shared by cosine.hip and the variant harness
-// (bench/gemm_variants.hip).  Measured on MI355X (8189 x 8189 x 32768): 146.7 TFLOP/s = 93 % of the f32 MFMA peak.
+// (bench/gemm_variants.hip).  Two element types, one kernel:
+//     F16 = false  exact fp32: v_mfma_f32_32x32x2_f32, BK = 32 floats.  Shipped 128x128 tile, 4 waves, 2 workgroups
+//                  per CU (two waves per SIMD from DIFFERENT workgroups: one computes while the other syncs).
+//                  Measured 8189 x 8189 x 32768: 146.7 TFLOP/s = 93 % of the f32 MFMA peak.
+//     F16 = true   fp16 operands, fp32 accumulate: v_mfma_f32_32x32x16_f16, BK = 64 halfs.  Same bytes per k-tile
+//                  row (128 B), so the LDS image, the swizzle and the loader are shared.
 //
-//   * v_mfma_f32_32x32x2_f32, wave tile (32*MI) x (32*NI), block tile BM x BN, BK = 32; shipped: 128x128, 4 waves,
-//     2 workgroups per CU (two waves per SIMD from DIFFERENT workgroups, so one computes while the other syncs).
+//   * wave tile (32*MI) x (32*NI), block tile BM x BN, k-tile = 128 B per row.
 //   * operands stream HBM -> LDS with 16-B-per-lane LDS-DMA; one wave-instruction fills 8 rows x 128 B.  The LDS image
 //     is XOR-swizzled through the per-lane SOURCE offset (chunk ^= (row >> 1) & 7) with the same XOR on the
 //     ds_read_b128: conflict-free 16-lane read groups.
@@ -41,10 +45,10 @@ struct GemmTile {
 };
 
 struct GemmArgs {
-  const float* A;
-  const float* B;
-  int64_t M, N, L;
-  int64_t lda, ldb;  // row strides in floats (>= L)
+  const void* A;     // fp32 or fp16 rows
+  const void* B;
+  int64_t M, N, L;   // L in elements
+  int64_t lda, ldb;  // row strides in elements (>= L)
   const float* inva;
   const float* invb;
   float* out;
@@ -57,16 +61,20 @@ struct GemmArgs {
   unsigned long long* stamps;  // diagnostic builds only (STAMP)
 };
 
-constexpr int GEMM_BK = 32;
-constexpr int GEMM_KBLOCK = 1024;
+constexpr int GEMM_ROW_BYTES = 128;  // bytes of one operand row in a k-tile
+constexpr int GEMM_KBLOCK = 1024;    // k-values per MFMA accumulation chain (two-level summation)
 enum { GEMM_MODE_FULL = 0, GEMM_MODE_PARTIAL = 1, GEMM_MODE_REDUCE = 2 };
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool F16 = false>
 struct GemmCfg {
+  static constexpr int ESZ = F16 ? 2 : 4;
+  static constexpr int BK = GEMM_ROW_BYTES / ESZ;  // k-values per k-tile: 32 floats or 64 halfs
   static constexpr int THREADS = 64 * WM * WN;
   static constexpr int WAVES = WM * WN;
   static constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
-  static constexpr int A_BYTES = BM * GEMM_BK * 4, B_BYTES = BN * GEMM_BK * 4;
+  static constexpr int A_BYTES = BM * GEMM_ROW_BYTES, B_BYTES = BN * GEMM_ROW_BYTES;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;            // wave-instructions per tile
   static constexpr int LOADS_PER_WAVE = (A_INSTR + B_INSTR) / WAVES;  // per k-tile
@@ -116,7 +124,7 @@ struct GemmLoader {
   static constexpr int LPW = Cfg::LOADS_PER_WAVE;
   const char* base;    // this wave's operand (A or B) at the tile's first row, minus 3 KiB (keeps voff >= 0)
   unsigned voff[LPW];  // per-lane byte offset from base (row * ld * 4 + swizzled chunk * 16 + 3 KiB - (q&3) KiB)
-  unsigned gc4[LPW];   // 4 * swizzled chunk (floats): k-tail check only
+  unsigned gce[LPW];   // first element of the swizzled 16-B chunk inside the k-tile: k-tail check only
   int wave_base;       // byte offset of this wave's first load inside a stage buffer
   bool is_a;
 
@@ -124,7 +132,7 @@ struct GemmLoader {
     wave_base = wave * LPW * 1024;
     is_a = wave * LPW < Cfg::A_INSTR;
     const int64_t row0 = is_a ? m0 : n0, nrows = is_a ? g.M : g.N, ld = is_a ? g.lda : g.ldb;
-    base = reinterpret_cast<const char*>((is_a ? g.A : g.B) + row0 * ld) - 3072;
+    base = static_cast<const char*>(is_a ? g.A : g.B) + row0 * ld * Cfg::ESZ - 3072;
 #pragma unroll
     for (int q = 0; q < LPW; ++q) {
       const int inst = wave * LPW + q;
@@ -132,18 +140,20 @@ struct GemmLoader {
       const int gc = (lane & 7) ^ ((r >> 1) & 7);
       int64_t grow = row0 + r;
       grow = grow < nrows ? grow : nrows - 1;  // rows past the edge are computed and discarded
-      voff[q] = (unsigned)((grow - row0) * ld * 4 + 16 * gc + 3072 - (q & 3) * 1024);
-      gc4[q] = 4 * gc;
+      voff[q] = (unsigned)((grow - row0) * ld * Cfg::ESZ + 16 * gc + 3072 - (q & 3) * 1024);
+      gce[q] = (16 / Cfg::ESZ) * gc;
     }
   }
 
-  // full tile: no VALU, no compiler-visible load (the caller counts vmcnt by hand)
-  template <int Q0 = 0>
+  // full tile, loads [Q0, Q1): no VALU, no compiler-visible load (the caller counts vmcnt by hand).  Groups of <= 4
+  // loads aligned to multiples of 4 share one M0 / one scalar base.
+  template <int Q0, int Q1>
   __device__ __forceinline__ void issue(int64_t k0, char* stage) const {
-    if constexpr (Q0 < LPW) {
-      constexpr int GE = Q0 + 4 < LPW ? Q0 + 4 : LPW;
-      const char* sb = base + k0 * 4;
-      const unsigned m0v = lds_addr(stage + wave_base + Q0 * 1024);
+    if constexpr (Q0 < Q1) {
+      constexpr int GE = ((Q0 & ~3) + 4) < Q1 ? ((Q0 & ~3) + 4) : Q1;
+      constexpr int I0 = (Q0 & 3) * 1024;  // immediate of the first load of this (possibly partial) group
+      const char* sb = base + k0 * Cfg::ESZ;
+      const unsigned m0v = lds_addr(stage + wave_base + (Q0 & ~3) * 1024);
       if constexpr (GE - Q0 == 4)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %2, %1\n\t"
@@ -152,23 +162,29 @@ struct GemmLoader {
                      "global_load_lds_dwordx4 %5, %1 offset:3072"
                      ::"s"(m0v), "s"(sb), "v"(voff[Q0]), "v"(voff[Q0 + 1]), "v"(voff[Q0 + 2]), "v"(voff[Q0 + 3])
                      : "memory");
-      else if constexpr (GE - Q0 == 2)
+      else if constexpr (GE - Q0 == 2 && I0 == 0)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %2, %1\n\t"
                      "global_load_lds_dwordx4 %3, %1 offset:1024"
                      ::"s"(m0v), "s"(sb), "v"(voff[Q0]), "v"(voff[Q0 + 1])
                      : "memory");
+      else if constexpr (GE - Q0 == 2 && I0 == 2048)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %1 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %3, %1 offset:3072"
+                     ::"s"(m0v), "s"(sb), "v"(voff[Q0]), "v"(voff[Q0 + 1])
+                     : "memory");
       else
-        static_assert(GE - Q0 == 4, "LOADS_PER_WAVE must be 4k or 4k+2");
-      issue<GE>(k0, stage);
+        static_assert(GE - Q0 == 4, "unsupported LDS-DMA group shape");
+      issue<GE, Q1>(k0, stage);
     }
   }
 
-  // last k-tile when L % 32 != 0: 16-B chunks at or past L come from a zero buffer (builtin path, rare)
+  // last k-tile when L % BK != 0: 16-B chunks at or past L come from a zero buffer (builtin path, rare)
   __device__ __forceinline__ void issue_checked(const GemmArgs& g, int64_t k0, char* stage) const {
 #pragma unroll
     for (int q = 0; q < LPW; ++q) {
-      const char* p = (k0 + gc4[q] < g.L) ? base + k0 * 4 + (size_t)voff[q] + (q & 3) * 1024
+      const char* p = (k0 + gce[q] < g.L) ? base + k0 * Cfg::ESZ + (size_t)voff[q] + (q & 3) * 1024
                                           : reinterpret_cast<const char*>(g.zero16);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                        (__attribute__((address_space(3))) void*)(stage + wave_base + q * 1024), 16, 0, 0);
@@ -177,9 +193,13 @@ struct GemmLoader {
 };
 
 // OCC = minimum waves per SIMD the register allocator must leave room for (blocks per CU * threads / 256)
-template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, int MODE = GEMM_MODE_FULL, bool STAMP = false>
-__global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_f32_kernel(GemmArgs g) {
-  using Cfg = GemmCfg<BM, BN, WM, WN, STAGES>;
+// TWO = two-level accumulation (needed for fp32-grade sums; off for the fp16 path, whose input rounding dominates)
+// ILV = spread the next tile's LDS-DMA issue over the four k-steps of the current tile instead of one burst
+template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, int MODE = GEMM_MODE_FULL, bool STAMP = false,
+          bool F16 = false, bool TWO = true, bool ILV = false>
+__global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g) {
+  using Cfg = GemmCfg<BM, BN, WM, WN, STAGES, F16>;
+  constexpr int GEMM_BK = Cfg::BK;
   constexpr int MI = Cfg::MI, NI = Cfg::NI;
   static_assert(!SYMM || BM == BN, "the mirrored store needs square tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,13 +238,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_f32_kernel(GemmArgs g)
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   if constexpr (MODE != GEMM_MODE_REDUCE) {
-    f32x16_t tot[MI][NI];
+    f32x16_t tot[TWO ? MI : 1][TWO ? NI : 1];
+    if constexpr (TWO) {
 #pragma unroll
-    for (int a = 0; a < MI; ++a)
+      for (int a = 0; a < MI; ++a)
 #pragma unroll
-      for (int b = 0; b < NI; ++b)
+        for (int b = 0; b < NI; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tot[a][b][r] = 0.f;
+          for (int r = 0; r < 16; ++r) tot[a][b][r] = 0.f;
+    }
 
     const int nk_all = (int)((g.L + GEMM_BK - 1) / GEMM_BK);
     int kt0 = 0, kt1 = nk_all;
@@ -239,7 +261,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_f32_kernel(GemmArgs g)
     auto stage_tile = [&](int t) {
       char* st = smem + ((t - kt0) % STAGES) * Cfg::STAGE_BYTES;
       if (ktail && t == nk_all - 1) ld.issue_checked(g, (int64_t)t * GEMM_BK, st);
-      else ld.issue((int64_t)t * GEMM_BK, st);
+      else ld.template issue<0, Cfg::LOADS_PER_WAVE>((int64_t)t * GEMM_BK, st);
     };
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -270,7 +292,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_f32_kernel(GemmArgs g)
       if constexpr (STAMP) s1 = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_barrier();
       if constexpr (STAMP) s2 = __builtin_amdgcn_s_memtime();
-      if (kt + STAGES - 1 < kt1) stage_tile(kt + STAGES - 1);
+      const int tnext = kt + STAGES - 1;
+      const bool inl = ILV && tnext < kt1 && !(ktail && tnext == nk_all - 1);  // interleave only full tiles
+      if (tnext < kt1 && !inl) stage_tile(tnext);
       if constexpr (STAMP) s3 = __builtin_amdgcn_s_memtime();
       const unsigned base = lds0 + ((kt - kt0) % STAGES) * Cfg::STAGE_BYTES;
       f32x4_t av[2][MI], bv[2][NI];
@@ -286,18 +310,38 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_f32_kernel(GemmArgs g)
           for (int a = 0; a < MI; ++a) ds_read_frag(av[n][a], base + offa[a][t + 1]);
 #pragma unroll
           for (int b = 0; b < NI; ++b) ds_read_frag(bv[n][b], base + offb[b][t + 1]);
-          wait_lgkm<MI + NI>();  // the step-t fragments are back; the step-t+1 reads stay in flight
-        } else {
-          wait_lgkm<0>();
         }
+        if constexpr (ILV) {
+          if (inl) {
+            constexpr int QN = Cfg::LOADS_PER_WAVE;
+            char* st = smem + ((tnext - kt0) % STAGES) * Cfg::STAGE_BYTES;
+            const int64_t k0n = (int64_t)tnext * GEMM_BK;
+            if (t == 0) ld.template issue<0, QN / 4>(k0n, st);
+            if (t == 1) ld.template issue<QN / 4, QN / 2>(k0n, st);
+            if (t == 2) ld.template issue<QN / 2, 3 * QN / 4>(k0n, st);
+            if (t == 3) ld.template issue<3 * QN / 4, QN>(k0n, st);
+          }
+        }
+        if (t < 3) wait_lgkm<MI + NI>();  // the step-t fragments are back; the step-t+1 reads stay in flight
+        else wait_lgkm<0>();
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        if constexpr (F16) {
+          // one 16-B fragment = 8 halfs = this lane's k-slice of a 32x32x16 MFMA (k = 16*t + 8*h + j)
 #pragma unroll
           for (int a = 0; a < MI; ++a)
 #pragma unroll
             for (int b = 0; b < NI; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][a][e], bv[c][b][e], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, av[c][a]),
+                                                                 __builtin_bit_cast(f16x8_t, bv[c][b]), acc[a][b], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+              for (int b = 0; b < NI; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][a][e], bv[c][b][e], acc[a][b], 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -305,15 +349,17 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_f32_kernel(GemmArgs g)
         const unsigned long long s4 = __builtin_amdgcn_s_memtime();
         seg[0] += s1 - s0; seg[1] += s2 - s1; seg[2] += s3 - s2; seg[3] += s4 - s3;
       }
-      if (((kt - kt0) & (GEMM_KBLOCK / GEMM_BK - 1)) == GEMM_KBLOCK / GEMM_BK - 1) {
+      if constexpr (TWO) {
+        if (((kt - kt0) & (GEMM_KBLOCK / GEMM_BK - 1)) == GEMM_KBLOCK / GEMM_BK - 1) {
 #pragma unroll
-        for (int a = 0; a < MI; ++a)
+          for (int a = 0; a < MI; ++a)
 #pragma unroll
-          for (int b = 0; b < NI; ++b) {
-            tot[a][b] += acc[a][b];
+            for (int b = 0; b < NI; ++b) {
+              tot[a][b] += acc[a][b];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-          }
+              for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            }
+        }
       }
     }
     if constexpr (STAMP) {
@@ -324,10 +370,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_f32_kernel(GemmArgs g)
         o[4] = seg[0]; o[5] = seg[1]; o[6] = seg[2]; o[7] = seg[3];
       }
     }
+    if constexpr (TWO) {
 #pragma unroll
-    for (int a = 0; a < MI; ++a)
+      for (int a = 0; a < MI; ++a)
 #pragma unroll
-      for (int b = 0; b < NI; ++b) acc[a][b] += tot[a][b];
+        for (int b = 0; b < NI; ++b) acc[a][b] += tot[a][b];
+    }
   }
 
   // raw accumulator image of a block: [wave][a*NI+b][reg][lane]  (256-B coalesced rows)

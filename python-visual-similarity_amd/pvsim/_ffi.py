@@ -64,6 +64,9 @@ SIGNATURES = {
     "pvs_cosine_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64],
     "pvs_topk_dev": [_vp, _vp, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp],
     "pvs_cosine_topk_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _i64, _int, _vp, _vp],
+    "pvs_f32_to_f16_dev": [_vp, _vp, _i64, _vp],
+    "pvs_cosine_f16_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64],
+    "pvs_cosine_topk_f16_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _i64, _int, _vp, _vp],
     "pvs_cosine_topk": [_vp, _vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
     "pvs_topk_merge_dev": [_vp, _vp, _vp, _int, _i64, _int, _vp, _vp],
     "pvs_timers_enable": [_vp, _int],

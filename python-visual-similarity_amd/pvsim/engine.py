@@ -247,6 +247,16 @@ class Context:
         check(_ffi.lib().pvs_cosine_topk_dev(self.handle, ptr(d_q), nq, ptr(d_db), N, L, ptr(d_invq), ptr(d_invdb), k,
                                              col_offset, int(merge), ptr(d_idx), ptr(d_val)))
 
+    def f32_to_f16_dev(self, d_src, n, d_dst):
+        check(_ffi.lib().pvs_f32_to_f16_dev(self.handle, ptr(d_src), n, ptr(d_dst)))
+
+    def cosine_f16_dev(self, d_a, M, d_b, N, L, d_inva, d_invb, d_out, ldo):
+        check(_ffi.lib().pvs_cosine_f16_dev(self.handle, ptr(d_a), M, ptr(d_b), N, L, ptr(d_inva), ptr(d_invb), ptr(d_out), ldo))
+
+    def cosine_topk_f16_dev(self, d_q, nq, d_db, N, L, d_invq, d_invdb, k, col_offset, merge, d_idx, d_val):
+        check(_ffi.lib().pvs_cosine_topk_f16_dev(self.handle, ptr(d_q), nq, ptr(d_db), N, L, ptr(d_invq), ptr(d_invdb), k,
+                                                 col_offset, int(merge), ptr(d_idx), ptr(d_val)))
+
     def topk_merge_dev(self, d_idx_lists, d_val_lists, n_lists, nq, k, d_idx, d_val):
         check(_ffi.lib().pvs_topk_merge_dev(self.handle, ptr(d_idx_lists), ptr(d_val_lists), n_lists, nq, k, ptr(d_idx),
                                             ptr(d_val)))

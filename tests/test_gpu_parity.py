@@ -352,3 +352,55 @@ def test_sharded_decomposition_on_one_gpu(gpu_ctx, world, n_total):
         got_val.append(val[:n_loc].cpu().numpy())
     assert np.array_equal(np.concatenate(got_idx), ref_idx)
     assert np.array_equal(np.concatenate(got_val), ref_val)
+
+
+# ======================================================================================= fp16 similarity (config 5)
+def test_fp16_cosine_and_recall(gpu_ctx, tables):
+    """fp16 operands, fp32 accumulate.  (1) exact check: on fp16-rounded inputs the kernel equals the fp64 dot of
+    those rounded values to fp32-accumulation accuracy; (2) recall@10 of the fp16 ranking against the exact fp32
+    ranking on VLAD encodings (BASELINE configs[4] correctness criterion)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(55)
+    counts = rng.integers(100, 700, 700)
+    raws = [synth.sift_like(int(n), rng).astype(np.uint8) for n in counts]
+    packed, offsets = pack_descriptors(raws, 128, np.uint8)
+    cb = gpu_ctx.codebook(tables["centroids"])
+    v = gpu_ctx.vlad_encode(cb, packed, offsets, DESC_U8_ROOTSIFT)           # (700, 32768) fp32
+    n, L = v.shape
+    t32 = torch.from_numpy(v).to(dev)
+    t16 = torch.empty((n, L), dtype=torch.float16, device=dev)
+    inv = torch.empty((n,), dtype=torch.float32, device=dev)
+    out = torch.empty((n, n), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.f32_to_f16_dev(t32.data_ptr(), n * L, t16.data_ptr())
+    gpu_ctx.row_inv_norms_dev(t32.data_ptr(), n, L, inv.data_ptr())
+    gpu_ctx.cosine_f16_dev(t16.data_ptr(), n, t16.data_ptr(), n, L, inv.data_ptr(), inv.data_ptr(), out.data_ptr(), n)
+    gpu_ctx.sync()
+    assert np.array_equal(t16.cpu().numpy(), v.astype(np.float16))          # conversion is round-to-nearest-even
+    h = v.astype(np.float16).astype(np.float64)
+    iv = inv.cpu().numpy().astype(np.float64)
+    ref16 = (h @ h.T) * iv[:, None] * iv[None, :]
+    got = out.cpu().numpy()
+    assert np.abs(got - ref16).max() < 5e-6
+    assert np.array_equal(got, got.T)                                       # symmetric mode: bitwise symmetric
+    # general (non-symmetric) launch agrees with the symmetric one
+    out2 = torch.empty((100, n), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.cosine_f16_dev(t16[300:].data_ptr(), 100, t16.data_ptr(), n, L, inv[300:].data_ptr(), inv.data_ptr(),
+                           out2.data_ptr(), n)
+    gpu_ctx.sync()
+    assert np.abs(out2.cpu().numpy() - got[300:400]).max() < 1e-6
+    # recall@10 vs exact fp32
+    k = 10
+    idx16 = torch.empty((n, k), dtype=torch.int64, device=dev)
+    val16 = torch.empty((n, k), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.cosine_topk_f16_dev(t16.data_ptr(), n, t16.data_ptr(), n, L, inv.data_ptr(), inv.data_ptr(), k, 0, False,
+                                idx16.data_ptr(), val16.data_ptr())
+    gpu_ctx.sync()
+    idx32, _ = gpu_ctx.cosine_topk(v, v, k)
+    i16 = idx16.cpu().numpy()
+    recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(i16, idx32)])
+    print(f"fp16 recall@{k} vs fp32: {recall:.4f}")
+    assert recall >= 0.99 and np.array_equal(i16[:, 0], np.arange(n))
