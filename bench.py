@@ -56,6 +56,11 @@ def parse():
     ap.add_argument("--images", type=int, default=8189)
     ap.add_argument("--desc", choices=["f32", "u8"], default="f32",
                     help="descriptor rows in HBM: fp32 RootSIFT (default) or raw uint8 SIFT with fused RootSIFT")
+    ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim"], default="config2",
+                    help="config2 = the headline line (default).  Side workloads (single GPU, same JSON shape, not the "
+                         "headline): fisher = BASELINE configs[2] (Fisher D=512 K=256 n=196), vlad512 = the per-GPU share of "
+                         "configs[3] (n=512 descriptors per image, encode only), fp16sim = configs[4] scaled to one GPU "
+                         "(N x N cosine on fp16 encodings + top-10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time one step with host-resident inputs (H2D included)")
     return ap.parse_args()
@@ -96,8 +101,137 @@ def rootsift_torch(raw_u8):
     return out
 
 
+def side_workload(args):
+    """Single-GPU measurements of the other BASELINE configs (same timing discipline, separate JSON line)."""
+    import torch
+    import pvsim
+    from pvsim.engine import DESC_F32, DESC_U8_ROOTSIFT
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx = pvsim.Context(0)
+    tables = np.load(os.path.join(REPO, "tests", "golden", "tables_k256_d128.npz"), allow_pickle=False)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1236)
+    N = args.images
+    out = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "data": "synthetic",
+           "vs_baseline": None, "device": ctx.device_name()}
+
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        ctx.sync(); torch.cuda.synchronize()
+        ctx.timers_enable(True); ctx.timers_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        ctx.sync(); torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        tm = ctx.timers(); ctx.timers_enable(False)
+        return dt, {k: round(v[0] / args.steps, 4) for k, v in tm.items() if v[1]}
+
+    if args.workload == "fisher":
+        K, D, n = 256, 512, 196
+        rng = np.random.default_rng(1236)
+        means = rng.normal(0.0, 2.0, size=(K, D))
+        cov = np.exp(rng.uniform(np.log(1e-3), np.log(25.0), size=(K, D)))
+        w = rng.dirichlet(np.full(K, 5.0))
+        gm = ctx.gmm(w, means, cov)
+        z = torch.randint(0, K, (N * n,), generator=g, device=dev)
+        desc = (torch.from_numpy(means.astype(np.float32)).to(dev)[z]
+                + torch.from_numpy(np.sqrt(cov).astype(np.float32)).to(dev)[z] * torch.randn((N * n, D), generator=g, device=dev))
+        off = torch.arange(0, N + 1, dtype=torch.int64, device=dev) * n
+        L = K + 2 * K * D
+        enc = torch.empty((N, L), dtype=torch.float32, device=dev)
+        inv = torch.empty((N,), dtype=torch.float32, device=dev)
+        idx = torch.empty((N, TOPK), dtype=torch.int64, device=dev)
+        val = torch.empty((N, TOPK), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        chunk = 32768
+
+        def step():
+            for s0 in range(0, N, chunk):
+                e0 = min(N, s0 + chunk)
+                ctx.fisher_encode_dev(gm, desc[s0 * n:].data_ptr(), DESC_F32, (off[s0:e0 + 1] - off[s0]).contiguous().data_ptr(),
+                                      e0 - s0, (e0 - s0) * n, enc[s0:].data_ptr(), 0)
+            ctx.row_inv_norms_dev(enc.data_ptr(), N, L, inv.data_ptr())
+            ctx.cosine_topk_dev(enc.data_ptr(), N, enc.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(), TOPK, 0, False,
+                                idx.data_ptr(), val.data_ptr())
+        dt, st = timed(step)
+        assert np.array_equal(idx[:, 0].cpu().numpy(), np.arange(N))
+        enc_ms = st.get("fisher_posterior", 0) + st.get("fisher_moments", 0)
+        out.update({"metric": "images/sec encoded + top-k retrieved, Fisher K256 D512 n196 (BASELINE configs[2])",
+                    "value": round(N / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "f64",
+                    "scaling": "strong", "stages_ms_per_step": st,
+                    "config": {"workload": f"{N} images x {n} x {D}-D descriptors, diag GMM K={K}: Fisher encode (fp64 "
+                                           f"arithmetic, fp32 stored) + {N}x{N} cosine + top-{TOPK}", "K": K, "D": D},
+                    "encode_GFLOPs_fp64": round(8.0 * n * K * D * N / (enc_ms * 1e-3) / 1e9, 1) if enc_ms else None})
+    elif args.workload == "vlad512":
+        n = 512
+        cb = ctx.codebook(tables["centroids"])
+        from pvsim import synth
+        proto = torch.from_numpy(synth.sift_prototypes().astype(np.float32)).to(dev)
+        raw = torch.empty((N * n, DIM), dtype=torch.uint8, device=dev)
+        for s0 in range(0, N * n, 1 << 20):
+            e0 = min(N * n, s0 + (1 << 20))
+            z = torch.randint(0, proto.shape[0], (e0 - s0,), generator=g, device=dev)
+            x = proto[z] * torch.exp(0.35 * torch.randn((e0 - s0, DIM), generator=g, device=dev)) + \
+                4.8 * torch.rand((e0 - s0, DIM), generator=g, device=dev) ** 3
+            raw[s0:e0] = (x * (512.0 / x.norm(dim=1, keepdim=True).clamp_min(1e-9))).clamp_max(255.0).round().to(torch.uint8)
+        desc = raw if args.desc == "u8" else rootsift_torch(raw)
+        kind = DESC_U8_ROOTSIFT if args.desc == "u8" else DESC_F32
+        off = torch.arange(0, N + 1, dtype=torch.int64, device=dev) * n
+        L = K_CLUSTERS * DIM
+        enc = torch.empty((N, L), dtype=torch.float32, device=dev)
+        inv = torch.empty((N,), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        dt, st = timed(lambda: ctx.vlad_encode_dev(cb, desc.data_ptr(), kind, off.data_ptr(), N, N * n, enc.data_ptr(),
+                                                   d_inv_norm=inv.data_ptr()))
+        byt = N * (n * DIM * (1 if args.desc == "u8" else 4) + L * 4)
+        out.update({"metric": "images/sec VLAD-encoded, K256 D128 n512 (per-GPU share of BASELINE configs[3])",
+                    "value": round(N / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "f32",
+                    "scaling": "weak", "stages_ms_per_step": st,
+                    "config": {"workload": f"{N} images x 512 SIFT-like descriptors ({args.desc}), VLAD K=256 encode only"},
+                    "roofline": {"kernel": "assign_kernel", "bound": "mfma",
+                                 "achieved": round(2.0 * N * n * K_CLUSTERS * DIM / (st["assign"] * 1e-3) / 1e12, 2),
+                                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(2.0 * N * n * K_CLUSTERS * DIM / (st["assign"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                 "traffic": None},
+                    "encode_algorithmic_GBps": round(byt / dt / 1e9, 1)})
+    else:  # fp16sim
+        L, k = K_CLUSTERS * DIM, 10
+        # VLAD-like rows: 256 unit-norm 128-d blocks, ~35 % of them empty
+        enc = torch.randn((N, K_CLUSTERS, DIM), generator=g, device=dev)
+        enc = enc / enc.norm(dim=2, keepdim=True)
+        enc = (enc * (torch.rand((N, K_CLUSTERS, 1), generator=g, device=dev) > 0.35)).reshape(N, L).contiguous()
+        e16 = torch.empty((N, L), dtype=torch.float16, device=dev)
+        inv = torch.empty((N,), dtype=torch.float32, device=dev)
+        idx = torch.empty((N, k), dtype=torch.int64, device=dev)
+        val = torch.empty((N, k), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        ctx.f32_to_f16_dev(enc.data_ptr(), N * L, e16.data_ptr())
+        ctx.row_inv_norms_dev(enc.data_ptr(), N, L, inv.data_ptr())
+        ctx.sync()
+        del enc
+        dt, st = timed(lambda: ctx.cosine_topk_f16_dev(e16.data_ptr(), N, e16.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(),
+                                                       k, 0, False, idx.data_ptr(), val.data_ptr()))
+        assert np.array_equal(idx[:, 0].cpu().numpy(), np.arange(N))
+        flop = 2.0 * N * N * L
+        out.update({"metric": "query rows/sec, N x N cosine on fp16 encodings + top-10 (BASELINE configs[4] on one GPU)",
+                    "value": round(N / dt, 1), "unit": "rows/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "f16",
+                    "scaling": "strong", "stages_ms_per_step": st,
+                    "config": {"workload": f"{N} x {N} cosine, L = {L} fp16, fp32 accumulate, top-{k}"},
+                    "roofline": {"kernel": "gemm_mfma_kernel<256,256,f16>", "bound": "mfma",
+                                 "achieved": round(flop / (st["cosine_gemm"] * 1e-3) / 1e12, 1), "peak": 2500.0,
+                                 "unit": "TFLOP/s (algorithmic 2*N*N*L; panels on the diagonal run symmetric)",
+                                 "frac": round(flop / (st["cosine_gemm"] * 1e-3) / 1e12 / 2500.0, 4), "traffic": None}})
+    print(json.dumps(out))
+    ctx.close()
+
+
 def main():
     args = parse()
+    if args.workload != "config2":
+        return side_workload(args)
     import torch
     import torch.distributed as dist
     import pvsim

@@ -235,7 +235,7 @@ PVS_EXPORT int pvs_gmm_create(pvs_ctx* ctx, const double* weights, const double*
   // derived tables, fp64, following sklearn/mixture/_gaussian_mixture.py:413-450,495-512 ('diag'):
   //   prec_chol = 1/sqrt(cov); precisions = prec_chol^2; log_det = sum log(prec_chol)
   //   const_k = -0.5*(D*log(2 pi) + sum_d mu^2 prec) + log_det + log(w_k)
-  std::vector<double> prec((size_t)K * D), mup((size_t)K * D), cst(K);
+  std::vector<double> prec((size_t)K * D), mup((size_t)K * D), cst(K), inv_mu((size_t)K * D), inv_sg((size_t)K * D);
   const double log2pi = std::log(2.0 * M_PI);
   for (int k = 0; k < K; ++k) {
     double s = 0.0, ld = 0.0;
@@ -247,6 +247,9 @@ PVS_EXPORT int pvs_gmm_create(pvs_ctx* ctx, const double* weights, const double*
       mup[i] = means[i] * p;
       s += means[i] * means[i] * p;
       ld += std::log(pc);
+      const double sw = std::sqrt(weights[k]);
+      inv_mu[i] = 1.0 / (sw * std::sqrt(covariances[i]));
+      inv_sg[i] = 1.0 / ((std::sqrt(2.0) * sw) * covariances[i]);
     }
     cst[k] = -0.5 * (D * log2pi + s) + ld + std::log(weights[k]);
   }
@@ -256,6 +259,8 @@ PVS_EXPORT int pvs_gmm_create(pvs_ctx* ctx, const double* weights, const double*
   if (st == PVS_OK) st = upload(ctx, &g->d_prec, prec.data(), prec.size());
   if (st == PVS_OK) st = upload(ctx, &g->d_mup, mup.data(), mup.size());
   if (st == PVS_OK) st = upload(ctx, &g->d_const, cst.data(), cst.size());
+  if (st == PVS_OK) st = upload(ctx, &g->d_inv_mu, inv_mu.data(), inv_mu.size());
+  if (st == PVS_OK) st = upload(ctx, &g->d_inv_sg, inv_sg.data(), inv_sg.size());
   if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
   if (st != PVS_OK) {
     pvs_gmm_destroy(ctx, g);
@@ -268,7 +273,7 @@ PVS_EXPORT int pvs_gmm_create(pvs_ctx* ctx, const double* weights, const double*
 PVS_EXPORT int pvs_gmm_destroy(pvs_ctx* ctx, pvs_gmm* g) {
   if (!g) return PVS_OK;
   if (ctx) hipStreamSynchronize(ctx->stream);
-  for (double* p : {g->d_w, g->d_mu, g->d_cov, g->d_prec, g->d_mup, g->d_const})
+  for (double* p : {g->d_w, g->d_mu, g->d_cov, g->d_prec, g->d_mup, g->d_const, g->d_inv_mu, g->d_inv_sg})
     if (p) hipFree(p);
   delete g;
   return PVS_OK;

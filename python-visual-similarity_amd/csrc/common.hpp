@@ -84,6 +84,8 @@ struct pvs_gmm {
   // derived, fp64 (sklearn/mixture/_gaussian_mixture.py:495-512)
   double* d_prec = nullptr;  // [K][D]  1/cov
   double* d_mup = nullptr;   // [K][D]  mu/cov
+  double* d_inv_mu = nullptr; // [K][D]  1/(sqrt(w) sqrt(cov))      (Fisher normalisation, fisher_vector.py:118-120)
+  double* d_inv_sg = nullptr; // [K][D]  1/(sqrt(2) sqrt(w) cov)
   double* d_const = nullptr; // [K]     -0.5*(D log 2pi + sum mu^2/cov) + sum log(1/sqrt(cov)) + log w
 };
 

@@ -14,6 +14,8 @@
 // makes the log-density a sum of large cancelling terms, so the device path keeps fp64 arithmetic
 // (MI355X runs fp64 at half the fp32 rate -- cheaper than losing 3 digits).  Round-1 kernels use vector
 // fp64 FMA with LDS-broadcast operands; v_mfma_f64_16x16x4 is the planned upgrade.
+#include <algorithm>
+
 #include "common.hpp"
 #include "desc_load.hpp"
 
@@ -212,15 +214,276 @@ static int posterior_on(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
   return PVS_OK;
 }
 
-int launch_gmm_posterior(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int kind, int ld, int64_t total,
-                         double* d_resp) {
-  if (total <= 0) return PVS_OK;
-  const void* x = d_desc;
-  int k = kind;
-  PVS_TRY(materialise_f32(ctx, x, k, total, g->D));
-  double* tabT = nullptr;
-  PVS_TRY(ws_reserve(ctx, 1, (size_t)2 * g->K * g->D * sizeof(double), reinterpret_cast<void**>(&tabT)));
-  return posterior_on(ctx, g, static_cast<const float*>(x), ld, total, d_resp, tabT);
+// ------------------------------------------------------------------------------------ fp64 MFMA building block
+// v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15] (one f64 per lane each),
+// C/D: 4 f64 per lane, col = lane&15, row = (lane>>4) + 4*reg.  Operand chunks sit in LDS as [row][KC+1] doubles
+// (the +1 makes the 16 rows of a fragment read hit distinct bank pairs).
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+constexpr int F64_KC = 16, F64_KCP = F64_KC + 1;
+
+template <int MI, int NI>
+__device__ __forceinline__ void f64_chunk_mma(const double* la, const double* lb, int arow0, int bcol0, int lane,
+                                              f64x4_t (&acc)[MI][NI]) {
+  const int r = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < F64_KC / 4; ++ks) {
+    double a[MI], b[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[mi] = la[(arow0 + 16 * mi + r) * F64_KCP + 4 * ks + kk];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b[ni] = lb[(bcol0 + 16 * ni + r) * F64_KCP + 4 * ks + kk];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------ K4 posterior on fp64 MFMA
+// logp[i][k] = const_k + [x_i | x_i**2] . [mu prec | -0.5 prec]_k      (one fp64 GEMM with inner dimension 2D)
+// Block = 32 descriptors x 256 cluster columns (4 waves x 64); K <= 256 (padded clusters get const = -inf).
+constexpr int PM_ROWS = 128, PM_COLS = 256, PM_THREADS = 512;
+
+struct PostMArgs {
+  const float* X;
+  int64_t total;
+  int D, ld, K;
+  const double* tab2;  // [K][2D]: mu*prec | -0.5*prec
+  const double* cst;   // [K]
+  double* resp;        // [total][K]
+};
+
+// 8 waves: wave = (wm, wn), wm = wave >> 2 owns descriptors [64 wm, +64), wn = wave & 3 owns clusters [64 wn, +64)
+__global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostMArgs a) {
+  __shared__ double la[PM_ROWS * F64_KCP];
+  __shared__ double lb[PM_COLS * F64_KCP];
+  __shared__ double red[PM_ROWS][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int64_t r0 = (int64_t)blockIdx.x * PM_ROWS;
+  const int kd = 2 * a.D;
+  f64x4_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+
+  for (int k0 = 0; k0 < kd; k0 += F64_KC) {
+    __syncthreads();
+    for (int idx = tid; idx < PM_ROWS * F64_KC; idx += PM_THREADS) {   // consecutive threads -> consecutive inner index
+      const int r = idx >> 4, j = k0 + (idx & 15);
+      double v = 0.0;
+      if (r0 + r < a.total && j < kd) {
+        const float x = a.X[(r0 + r) * a.ld + (j < a.D ? j : j - a.D)];
+        v = j < a.D ? (double)x : (double)(x * x);   // X**2 squared in fp32 first (sklearn _gaussian_mixture.py:500)
+      }
+      la[r * F64_KCP + (idx & 15)] = v;
+    }
+    for (int idx = tid; idx < PM_COLS * F64_KC; idx += PM_THREADS) {
+      const int c = idx >> 4, j = k0 + (idx & 15);
+      lb[c * F64_KCP + (idx & 15)] = (c < a.K && j < kd) ? a.tab2[(int64_t)c * kd + j] : 0.0;
+    }
+    __syncthreads();
+    f64_chunk_mma<4, 4>(la, lb, wm * 64, wn * 64, lane, acc);
+  }
+
+  // ---- softmax over clusters (scipy logsumexp: max, log-sum-exp, subtract, exp).  This lane holds, for column
+  // c = lane&15 of each of the wave's 4 cluster tiles, the 16 descriptor rows 64 wm + 16 mi + 4 reg + (lane>>4).
+  const int col = lane & 15, rq = lane >> 4;
+  double cst[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int k = wn * 64 + 16 * ni + col;
+    cst[ni] = k < a.K ? a.cst[k] : -INFINITY;
+  }
+  double mx[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double m = -INFINITY;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        acc[mi][ni][r] += cst[ni];
+        m = fmax(m, acc[mi][ni][r]);
+      }
+      for (int s = 8; s >= 1; s >>= 1) m = fmax(m, __shfl_xor(m, s, 64));  // over the 16 columns of this row group
+      if (col == 0) red[wm * 64 + 16 * mi + 4 * r + rq][wn] = m;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wm * 64 + 16 * mi + 4 * r + rq;
+      mx[mi][r] = fmax(fmax(red[row][0], red[row][1]), fmax(red[row][2], red[row][3]));
+    }
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) s += exp(acc[mi][ni][r] - mx[mi][r]);
+      for (int q = 8; q >= 1; q >>= 1) s += __shfl_xor(s, q, 64);
+      if (col == 0) red[wm * 64 + 16 * mi + 4 * r + rq][wn] = s;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wm * 64 + 16 * mi + 4 * r + rq;
+      const double lse = mx[mi][r] + log(((red[row][0] + red[row][1]) + red[row][2]) + red[row][3]);
+      if (r0 + row < a.total) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int k = wn * 64 + 16 * ni + col;
+          if (k < a.K) a.resp[(r0 + row) * a.K + k] = exp(acc[mi][ni][r] - lse);
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------ K5 on fp64 MFMA (fused)
+// Per image:  S[k][c] = sum_i gamma[i][k] * Z[i][c]  (inner dimension n_i), then the gradients, the power norm and
+// this block's share of the global norm -- the raw sums never leave the registers.
+// Block = (image, 64 dims), 8 waves: wave (wm = wave & 3, wn = wave >> 2) owns cluster rows [64 wm, +64) and the 64
+// columns Z = [x_d (32) | x_d**2 (32)] of dims d0 + 32 wn + [0, 32), so that the lane holding S1[k][d] (column tile
+// ni) also holds S2[k][d] (tile ni + 2).  s0[k] = sum_i gamma[i][k] is summed by thread k from the staged gamma^T
+// chunks (descriptor order).  The gamma^T chunk (32 KiB) is staged once per 128 columns.
+struct MomMArgs {
+  const float* X;
+  int D, ld, K;
+  const int64_t* offsets;
+  const double* resp;   // [total][K]
+  const double* w;
+  const double* mu;
+  const double* cov;
+  const double* inv_mu;   // [K][D]  1 / (sqrt(w_k) sqrt(cov_kd))
+  const double* inv_sg;   // [K][D]  1 / (sqrt(2) sqrt(w_k) cov_kd)
+  double power;
+  int norm_mode;
+  double norm_p;
+  void* out;
+  int out_f64;
+  double* partial;      // [n_images][dblocks]
+  int dblocks;
+};
+
+__device__ __forceinline__ double power_norm64(double v, double p);
+__device__ __forceinline__ double norm_term64(double v, int mode, double p);
+template <typename T>
+__device__ __forceinline__ void store_out(void* out, int f64, int64_t i, T v) {
+  if (f64) static_cast<double*>(out)[i] = (double)v;
+  else static_cast<float*>(out)[i] = (float)v;
+}
+
+constexpr int MM_THREADS = 512, MM_DIMS = 64;
+
+__global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomMArgs a) {
+  __shared__ double la[256 * F64_KCP];   // gamma^T chunk: [k][i]
+  __shared__ double lb[128 * F64_KCP];   // Z chunk:       [c][i], c = 64 wn + (x: 0..31 | x**2: 32..63)
+  __shared__ double s0s[256];
+  __shared__ double red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int img = blockIdx.y, dblk = blockIdx.x * MM_DIMS, d0 = dblk + 32 * wn;
+  const int64_t row0 = a.offsets[img];
+  const int n = (int)(a.offsets[img + 1] - row0);
+  const int K = a.K, D = a.D;
+  const int64_t L = (int64_t)K + 2 * (int64_t)K * D;
+  f64x4_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+  double s0 = 0.0;
+
+  for (int i0 = 0; i0 < n; i0 += F64_KC) {
+    __syncthreads();
+    for (int idx = tid; idx < 256 * F64_KC; idx += MM_THREADS) {  // consecutive threads -> consecutive clusters
+      const int ii = idx >> 8, k = idx & 255;
+      la[k * F64_KCP + ii] = (i0 + ii < n && k < K) ? a.resp[(row0 + i0 + ii) * K + k] : 0.0;
+    }
+    for (int idx = tid; idx < MM_DIMS * F64_KC; idx += MM_THREADS) {  // consecutive threads -> consecutive dims
+      const int ii = idx >> 6, dd = idx & 63, d = dblk + dd;
+      double v = 0.0, v2 = 0.0;
+      if (i0 + ii < n && d < D) {
+        const float x = a.X[(row0 + i0 + ii) * a.ld + d];
+        v = (double)x;
+        v2 = (double)(x * x);                                  // np.power(descriptors, 2) in fp32 (fisher_vector.py:104)
+      }
+      const int c = 64 * (dd >> 5) + (dd & 31);
+      lb[c * F64_KCP + ii] = v;
+      lb[(c + 32) * F64_KCP + ii] = v2;
+    }
+    __syncthreads();
+    if (tid < 256) {
+#pragma unroll
+      for (int ii = 0; ii < F64_KC; ++ii) s0 += la[tid * F64_KCP + ii];   // zeros past n
+    }
+    f64_chunk_mma<4, 4>(la, lb, wm * 64, wn * 64, lane, acc);
+  }
+  if (tid < 256) s0s[tid] = s0;
+  __syncthreads();
+
+  // Epilogue arithmetic: fp64 divisions and square roots cost tens of instructions each, and this epilogue is as long
+  // as the MFMA loop if written literally.  The per-(k,d) divisors 1/(sqrt(w) sqrt(cov)) and 1/(sqrt(2) sqrt(w) cov)
+  // come from tables built once per GMM, and /n becomes *(1/n): <= 2 ulp of fp64 from the literal formula.
+  double part = 0.0;
+  const int col = lane & 15, rq = lane >> 4;
+  const double dn = (double)(n > 0 ? n : 1), rdn = 1.0 / dn;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = wm * 64 + 16 * mi + 4 * r + rq;
+      if (k >= K) continue;
+      const double pp_sum = s0s[k] * rdn;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int d = d0 + 16 * ni + col;
+        if (d >= D) continue;
+        const int64_t o_mu = (int64_t)img * L + K + (int64_t)k * D + d, o_sg = o_mu + (int64_t)K * D;
+        if (n == 0) {   // empty image: zero row (the reference divides by zero; fenced quirk)
+          store_out(a.out, a.out_f64, o_mu, 0.0);
+          store_out(a.out, a.out_f64, o_sg, 0.0);
+          continue;
+        }
+        const int64_t kd_i = (int64_t)k * D + d;
+        const double mu = a.mu[kd_i], cv = a.cov[kd_i];
+        const double pp_x = acc[mi][ni][r] * rdn, pp_x2 = acc[mi][ni + 2][r] * rdn;
+        double d_mu = pp_x - pp_sum * mu;
+        double d_sg = ((-pp_x2 - pp_sum * (mu * mu)) + pp_sum * cv) + (2.0 * pp_x) * mu;
+        d_mu = power_norm64(d_mu * a.inv_mu[kd_i], a.power);
+        d_sg = power_norm64(d_sg * a.inv_sg[kd_i], a.power);
+        store_out(a.out, a.out_f64, o_mu, d_mu);
+        store_out(a.out, a.out_f64, o_sg, d_sg);
+        const double t1 = norm_term64(d_mu, a.norm_mode, a.norm_p), t2 = norm_term64(d_sg, a.norm_mode, a.norm_p);
+        part = a.norm_mode == 3 ? fmax(part, fmax(t1, t2)) : part + (t1 + t2);
+      }
+    }
+  if (blockIdx.x == 0 && tid < K) {   // d_pi (fisher_vector.py:107,117)
+    const double w = a.w[tid];
+    const double d_pi = n > 0 ? power_norm64((s0s[tid] / dn - w) / sqrt(w), a.power) : 0.0;
+    store_out(a.out, a.out_f64, (int64_t)img * L + tid, d_pi);
+    const double t = norm_term64(d_pi, a.norm_mode, a.norm_p);
+    part = a.norm_mode == 3 ? fmax(part, t) : part + t;
+  }
+  // deterministic block reduction of the norm term
+  for (int m = 32; m >= 1; m >>= 1) {
+    const double o = __shfl_xor(part, m, 64);
+    part = a.norm_mode == 3 ? fmax(part, o) : part + o;
+  }
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  if (tid == 0) {
+    double t = red[0];
+    for (int wv = 1; wv < 8; ++wv) t = a.norm_mode == 3 ? fmax(t, red[wv]) : t + red[wv];
+    a.partial[(int64_t)img * a.dblocks + blockIdx.x] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------ K5 moments + gradients
@@ -243,6 +506,8 @@ struct MomArgs {
   double* partial;     // [n_images][blocks_per_image]
   int blocks_per_image;
   int dblocks;
+  const double* S;     // PRE: [n_images][K][2D] raw sums from fisher_moments_mfma_kernel
+  const double* S0;    // PRE: [n_images][K]
 };
 
 __device__ __forceinline__ double power_norm64(double v, double p) {
@@ -256,7 +521,9 @@ __device__ __forceinline__ double norm_term64(double v, int mode, double p) {
   return mode == 2 ? v * v : (mode == 0 ? pow(av, p) : av);
 }
 
-template <int BT>
+// PRE = false: the sums are accumulated here with vector fp64 FMAs (any K);  PRE = true: the sums were produced by
+// the fp64-MFMA kernels and this kernel is only the gradient / power-norm / norm-partial epilogue.
+template <int BT, bool PRE>
 __global__ __launch_bounds__(BT) void fisher_moments_kernel(MomArgs a) {
   __shared__ double sg[MOM_IC][MOM_KB];
   __shared__ double red[BT / 64];
@@ -274,7 +541,20 @@ __global__ __launch_bounds__(BT) void fisher_moments_kernel(MomArgs a) {
 #pragma unroll
   for (int j = 0; j < MOM_KB; ++j) s0[j] = s1[j] = s2[j] = 0.0;
 
-  for (int i0 = 0; i0 < n; i0 += MOM_IC) {
+  if constexpr (PRE) {
+#pragma unroll
+    for (int j = 0; j < MOM_KB; ++j) {
+      const int k = k0 + j;
+      if (k < K) {
+        s0[j] = a.S0[(int64_t)img * K + k];
+        if (dv) {
+          s1[j] = a.S[((int64_t)img * K + k) * (2 * D) + d];
+          s2[j] = a.S[((int64_t)img * K + k) * (2 * D) + D + d];
+        }
+      }
+    }
+  }
+  for (int i0 = 0; !PRE && i0 < n; i0 += MOM_IC) {
     __syncthreads();
     for (int idx = tid; idx < MOM_IC * MOM_KB; idx += BT) {
       const int ii = idx / MOM_KB, j = idx % MOM_KB;
@@ -390,46 +670,121 @@ __global__ __launch_bounds__(256) void fisher_scale_kernel(void* out, int out_f6
   }
 }
 
-int launch_fisher(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int kind, int ld, const int64_t* d_offsets,
-                  int64_t n_images, int64_t total, const pvs_norm_params& prm, void* d_out, int out_f64) {
-  if (n_images <= 0) return PVS_OK;
-  if (n_images > 65535) PVS_FAIL(PVS_ERR_UNSUPPORTED, "fisher: at most 65535 images per call (got %lld); batch the call",
-                                (long long)n_images);
+__global__ void build_tab2_kernel(const double* __restrict__ prec, const double* __restrict__ mup, int K, int D,
+                                  double* __restrict__ tab2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)K * D) return;
+  const int k = (int)(i / D), d = (int)(i % D);
+  tab2[(int64_t)k * 2 * D + d] = mup[i];
+  tab2[(int64_t)k * 2 * D + D + d] = -0.5 * prec[i];
+}
+
+static int posterior_mfma_on(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, int64_t total, double* d_resp,
+                             double* tab2) {
+  const int64_t kd = (int64_t)g->K * g->D;
+  hipLaunchKernelGGL(build_tab2_kernel, dim3((unsigned)((kd + 255) / 256)), dim3(256), 0, ctx->stream, g->d_prec, g->d_mup,
+                     g->K, g->D, tab2);
+  PostMArgs a{x, total, g->D, ld, g->K, tab2, g->d_const, d_resp};
+  ScopedTimer tm(ctx, T_FPOST);
+  hipLaunchKernelGGL(gmm_posterior_mfma_kernel, dim3((unsigned)((total + PM_ROWS - 1) / PM_ROWS)), dim3(PM_THREADS), 0, ctx->stream, a);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+int launch_gmm_posterior(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int kind, int ld, int64_t total,
+                         double* d_resp) {
+  if (total <= 0) return PVS_OK;
   const void* x = d_desc;
   int k = kind;
   PVS_TRY(materialise_f32(ctx, x, k, total, g->D));
+  double* tab = nullptr;
+  PVS_TRY(ws_reserve(ctx, 1, (size_t)2 * g->K * g->D * sizeof(double), reinterpret_cast<void**>(&tab)));
+  if (g->K <= PM_COLS) return posterior_mfma_on(ctx, g, static_cast<const float*>(x), ld, total, d_resp, tab);
+  return posterior_on(ctx, g, static_cast<const float*>(x), ld, total, d_resp, tab);
+}
+
+// one batch of images (offsets are absolute descriptor rows; the batch's descriptors are rows [t0, t0 + tn))
+static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, const int64_t* d_offsets, int64_t img0,
+                        int64_t n_img, int64_t t0, int64_t tn, const pvs_norm_params& prm, void* d_out, int out_f64,
+                        char* ws, size_t tab_b, size_t resp_b) {
   const int K = g->K, D = g->D;
+  const bool mfma = K <= PM_COLS;
   const int bt = D <= 128 ? 128 : 256;
-  const int dblocks = (D + bt - 1) / bt, kblocks = (K + MOM_KB - 1) / MOM_KB;
+  const int dblocks = mfma ? (D + MM_DIMS - 1) / MM_DIMS : (D + bt - 1) / bt;
+  const int kblocks = mfma ? 1 : (K + MOM_KB - 1) / MOM_KB;
   const int bpi = dblocks * kblocks;
-  // workspace: transposed tables | responsibilities | norm partials
-  const size_t tab_b = ((size_t)2 * K * D * 8 + 255) / 256 * 256;
-  const size_t resp_b = ((size_t)std::max<int64_t>(total, 1) * K * 8 + 255) / 256 * 256;
-  const size_t part_b = (size_t)n_images * bpi * 8;
-  char* ws = nullptr;
-  PVS_TRY(ws_reserve(ctx, 1, tab_b + resp_b + part_b, reinterpret_cast<void**>(&ws)));
-  double* tabT = reinterpret_cast<double*>(ws);
+  double* tab = reinterpret_cast<double*>(ws);
   double* resp = reinterpret_cast<double*>(ws + tab_b);
   double* partial = reinterpret_cast<double*>(ws + tab_b + resp_b);
-  if (total > 0) PVS_TRY(posterior_on(ctx, g, static_cast<const float*>(x), ld, total, resp, tabT));
-
-  MomArgs a{};
-  a.X = static_cast<const float*>(x); a.D = D; a.ld = ld; a.K = K; a.offsets = d_offsets; a.resp = resp;
-  a.w = g->d_w; a.mu = g->d_mu; a.cov = g->d_cov; a.power = prm.power_norm_weight;
-  const double ord = prm.norm_order;
-  a.norm_mode = std::isinf(ord) ? 3 : (ord == 2.0 ? 2 : (ord == 1.0 ? 1 : 0));
-  a.norm_p = ord; a.out = d_out; a.out_f64 = out_f64; a.partial = partial; a.blocks_per_image = bpi; a.dblocks = dblocks;
   const int64_t L = (int64_t)K + 2 * (int64_t)K * D;
-  {
-    ScopedTimer tm(ctx, T_FMOM);
-    dim3 grid((unsigned)dblocks, (unsigned)kblocks, (unsigned)n_images);
-    if (bt == 128) hipLaunchKernelGGL(fisher_moments_kernel<128>, grid, dim3(128), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(fisher_moments_kernel<256>, grid, dim3(256), 0, ctx->stream, a);
-    PVS_HIP(hipGetLastError());
-    const unsigned sx = (unsigned)std::min<int64_t>((L + 255) / 256, 64);
-    hipLaunchKernelGGL(fisher_scale_kernel, dim3(sx, (unsigned)n_images), dim3(256), 0, ctx->stream, d_out, out_f64, L,
-                       partial, bpi, a.norm_mode, a.norm_p, prm.epsilon);
-    PVS_HIP(hipGetLastError());
+  double* resp_abs = resp - t0 * K;  // kernels index responsibilities by ABSOLUTE descriptor row
+  if (tn > 0) {
+    if (mfma) PVS_TRY(posterior_mfma_on(ctx, g, x + t0 * ld, ld, tn, resp, tab));
+    else PVS_TRY(posterior_on(ctx, g, x + t0 * ld, ld, tn, resp, tab));
+  }
+  const double ord = prm.norm_order;
+  const int norm_mode = std::isinf(ord) ? 3 : (ord == 2.0 ? 2 : (ord == 1.0 ? 1 : 0));
+  void* out_b = out_f64 ? static_cast<void*>(static_cast<double*>(d_out) + img0 * L)
+                        : static_cast<void*>(static_cast<float*>(d_out) + img0 * L);
+  ScopedTimer tm(ctx, T_FMOM);
+  if (mfma) {
+    MomMArgs m{x, D, ld, K, d_offsets + img0, resp_abs, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, prm.power_norm_weight, norm_mode, ord,
+               out_b, out_f64, partial, dblocks};
+    hipLaunchKernelGGL(fisher_moments_mfma_kernel, dim3((unsigned)dblocks, (unsigned)n_img), dim3(MM_THREADS), 0, ctx->stream, m);
+  } else {
+    MomArgs a{};
+    a.X = x; a.D = D; a.ld = ld; a.K = K; a.offsets = d_offsets + img0; a.resp = resp_abs;
+    a.w = g->d_w; a.mu = g->d_mu; a.cov = g->d_cov; a.power = prm.power_norm_weight;
+    a.norm_mode = norm_mode; a.norm_p = ord; a.out = out_b; a.out_f64 = out_f64; a.partial = partial;
+    a.blocks_per_image = bpi; a.dblocks = dblocks;
+    dim3 grid((unsigned)dblocks, (unsigned)kblocks, (unsigned)n_img);
+    if (bt == 128) hipLaunchKernelGGL((fisher_moments_kernel<128, false>), grid, dim3(128), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((fisher_moments_kernel<256, false>), grid, dim3(256), 0, ctx->stream, a);
+  }
+  PVS_HIP(hipGetLastError());
+  const unsigned sx = (unsigned)std::min<int64_t>((L + 255) / 256, 64);
+  hipLaunchKernelGGL(fisher_scale_kernel, dim3(sx, (unsigned)n_img), dim3(256), 0, ctx->stream, out_b, out_f64, L, partial, bpi,
+                     norm_mode, ord, prm.epsilon);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+int launch_fisher(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int kind, int ld, const int64_t* d_offsets,
+                  int64_t n_images, int64_t total, const pvs_norm_params& prm, void* d_out, int out_f64) {
+  if (n_images <= 0) return PVS_OK;
+  const void* xv = d_desc;
+  int k = kind;
+  PVS_TRY(materialise_f32(ctx, xv, k, total, g->D));
+  const float* x = static_cast<const float*>(xv);
+  const int K = g->K, D = g->D;
+  // Images go through in batches so that the responsibilities (fp64, n x K) and raw moment sums (K x 2D per image)
+  // stay within ~3 GiB of workspace.  Batch boundaries need the CSR offsets on the host.
+  std::vector<int64_t> off((size_t)n_images + 1);
+  PVS_HIP(hipMemcpyAsync(off.data(), d_offsets, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  const size_t per_img = 4096;
+  const size_t budget = (size_t)3 << 30;
+  const int bt = D <= 128 ? 128 : 256;
+  const int bpi = ((D + bt - 1) / bt) * ((K + MOM_KB - 1) / MOM_KB);
+  int64_t i0 = 0;
+  while (i0 < n_images) {
+    int64_t i1 = i0;
+    size_t bytes = 0;
+    while (i1 < n_images && i1 - i0 < 65535) {
+      const size_t add = per_img + (size_t)(off[i1 + 1] - off[i1]) * K * 8;
+      if (i1 > i0 && bytes + add > budget) break;
+      bytes += add;
+      ++i1;
+    }
+    const int64_t n_img = i1 - i0, t0 = off[i0], tn = off[i1] - off[i0];
+    const size_t tab_b = ((size_t)2 * K * D * 8 + 255) / 256 * 256;
+    const size_t resp_b = ((size_t)std::max<int64_t>(tn, 1) * K * 8 + 255) / 256 * 256;
+    const int dbl = K <= PM_COLS ? (D + MM_DIMS - 1) / MM_DIMS : bpi;
+    const size_t part_b = (size_t)n_img * std::max(dbl, bpi) * 8;
+    char* ws = nullptr;
+    PVS_TRY(ws_reserve(ctx, 1, tab_b + resp_b + part_b, reinterpret_cast<void**>(&ws)));
+    PVS_TRY(fisher_batch(ctx, g, x, ld, d_offsets, i0, n_img, t0, tn, prm, d_out, out_f64, ws, tab_b, resp_b));
+    i0 = i1;
   }
   return PVS_OK;
 }
