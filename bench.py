@@ -287,10 +287,11 @@ def main():
                             d_inv_norm=inv_loc.data_ptr())
         if world > 1:
             ctx.sync()                                   # encode (ctx stream) -> collective (torch stream)
+            pd.mask_padding(inv_loc, n_loc)              # padding rows of the last block(s): NaN inverse norm
             dist.all_gather_into_tensor(enc_all, enc_loc)
             dist.all_gather_into_tensor(inv_all, inv_loc)
             torch.cuda.current_stream().synchronize()
-        # score the local query block against every rank's block (true global indices, running top-k merge)
+        # score the local query block against the whole gathered corpus (one GEMM + select per rank)
         pd.retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, N, rank, world, TOPK, score_block, idx, val)
 
     def barrier():
@@ -331,14 +332,13 @@ def main():
     # the kernel computes only the upper triangle of 128x128 tiles and mirrors the rest, so the executed flop is
     # ~half of the algorithmic 2*N*M*L of SURVEY.md section 8(d); `achieved` counts executed flop only (never above peak).
     gemm_ms, gemm_n = timers["cosine_gemm"]
-    blk = min(per, N)
     t128 = (n_loc + 127) // 128
-    alg_flop = 2.0 * n_loc * blk * L
-    exec_tiles_sym = t128 * (t128 + 1) // 2
-    exec_flop_sym = 2.0 * 128 * 128 * L * exec_tiles_sym
-    exec_flop_full = 2.0 * 128 * 128 * L * t128 * ((blk + 127) // 128)
-    # per step: one symmetric launch (own block) + (world - 1) full launches
-    flop_per_launch = (exec_flop_sym + (world - 1) * exec_flop_full) / world
+    if world == 1:
+        alg_flop = 2.0 * N * N * L
+        flop_per_launch = 2.0 * 128 * 128 * L * (t128 * (t128 + 1) // 2)      # upper-triangle tiles
+    else:
+        alg_flop = 2.0 * n_loc * N * L
+        flop_per_launch = 2.0 * 128 * 128 * L * t128 * ((world * per + 127) // 128)
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flop_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
     traffic, traffic_src = pmc_traffic("pvs::gemm_f32_kernel")

@@ -4,10 +4,12 @@ blocks over RCCL/xGMI via torch.distributed), then every rank ranks its own quer
     rank r owns images [r*B, min(N, (r+1)*B)),  B = ceil(N / world)       (global index = r*B + local index,
                                                                            i.e. dict insertion order, eval.py:28)
 
-torch is plumbing here (device tensors + the collective).  The scoring itself is the C-ABI call
-`pvs_cosine_topk_dev` per gathered block, merged through its running top-k list, so padded rows of the last
-block are never scored and indices are true global indices.  The block loop is written against a `score_block`
-callable so that the same host logic runs under `gloo` on CPU in tests/test_dist_gloo.py.
+torch is plumbing here (device tensors + the collective).  The scoring itself is ONE C-ABI call
+`pvs_cosine_topk_dev` per rank (local queries x whole gathered corpus: a GEMM that fills the chip instead of
+`world` small ones).  Blocks have equal size B, so a row's position in the gathered array is its true global index;
+the trailing padding rows of the last block(s) carry a NaN inverse norm and therefore NaN scores, which the select
+kernel ranks last.  The logic is written against a `score_block` callable so that the same host code runs under
+`gloo` on CPU in tests/test_dist_gloo.py.
 """
 from __future__ import annotations
 
@@ -15,7 +17,7 @@ from typing import Callable
 
 import numpy as np
 
-__all__ = ["shard_range", "gather_blocks", "retrieve_sharded", "device_score_block", "ShardedVLADIndex"]
+__all__ = ["shard_range", "gather_blocks", "mask_padding", "retrieve_sharded", "device_score_block", "ShardedVLADIndex"]
 
 
 def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int, int]:
@@ -38,24 +40,29 @@ def gather_blocks(enc_loc, inv_loc, group=None):
     return enc_all, inv_all
 
 
+def mask_padding(inv_loc, n_loc: int) -> None:
+    """Mark the padding rows of a rank's block (rows >= n_loc) with a NaN inverse norm IN PLACE, before the
+    all-gather: their scores become NaN, which the select kernel ranks below every number, so they can never
+    displace a real image.  Because every block has the same size B and only trailing rows are padding, the row
+    position in the gathered (world*B, L) array IS the true global image index."""
+    if n_loc < inv_loc.shape[0]:
+        inv_loc[n_loc:] = float("nan")
+
+
 def retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, n_total: int, rank: int, world: int, k: int,
                      score_block: Callable, idx, val):
-    """Rank-local queries (rows [0, n_loc) of enc_loc) against every rank's block of enc_all.
+    """Rank-local queries (rows [0, n_loc) of enc_loc) against the whole gathered corpus in ONE scoring call.
 
-    score_block(q, n_q, db, n_db, inv_q, inv_db, k, col_offset, merge, idx, val) must merge the block's top-k into
-    (idx, val) when merge is true.  Returns the number of local queries."""
+    score_block(q, n_q, db, n_db, inv_q, inv_db, k, col_offset, merge, idx, val).  `inv_all` must carry NaN on
+    padding rows (mask_padding before the gather).  Returns the number of local queries."""
     lo, hi, block = shard_range(n_total, world, rank)
     n_loc = hi - lo
     if n_loc == 0:
         return 0
-    first = True
-    for s in range(world):
-        s_lo, s_hi, _ = shard_range(n_total, world, s)
-        if s_hi <= s_lo:
-            continue
-        score_block(enc_loc, n_loc, enc_all[s * block:], s_hi - s_lo, inv_loc, inv_all[s * block:], k, s_lo,
-                    not first, idx, val)
-        first = False
+    if world == 1:
+        score_block(enc_loc, n_loc, enc_all, n_loc, inv_loc, inv_all, k, 0, False, idx, val)   # symmetric path
+    else:
+        score_block(enc_loc, n_loc, enc_all, world * block, inv_loc, inv_all, k, 0, False, idx, val)
     return n_loc
 
 
@@ -92,6 +99,8 @@ class ShardedVLADIndex:
                                  self.enc_loc.data_ptr(), power, norm_order, epsilon,
                                  d_inv_norm=self.inv_loc.data_ptr())
         self.ctx.sync()
+        if self.world > 1:
+            mask_padding(self.inv_loc, n_loc)
         return self.enc_loc
 
     def exchange(self):

@@ -16,6 +16,7 @@ from conftest import REPO
 def _oracle_score_block(q, n_q, db, n_db, inv_q, inv_db, k, col_offset, merge, idx, val):
     import pvsim_oracle as orc
     s = orc.cosine_similarity(q[:n_q].numpy(), db[:n_db].numpy())
+    s = np.where(np.isnan(inv_db[:n_db].numpy())[None, :], -np.inf, s)   # padding rows (NaN inverse norm) rank last
     cand_idx = np.tile(np.arange(col_offset, col_offset + n_db), (n_q, 1))
     cand_val = s
     if merge:
@@ -44,6 +45,7 @@ def _worker(rank, world, port, n_total, k, out_dir):
     enc_loc = torch.zeros((block, 48), dtype=torch.float32)
     enc_loc[: hi - lo] = torch.from_numpy(enc[lo:hi])
     inv_loc = torch.ones((block,), dtype=torch.float32)
+    pd.mask_padding(inv_loc, hi - lo)
     enc_all, inv_all = pd.gather_blocks(enc_loc, inv_loc)
     assert enc_all.shape == (world * block, 48)
     idx = torch.full((block, k), -1, dtype=torch.int64)

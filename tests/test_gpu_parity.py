@@ -337,6 +337,10 @@ def test_sharded_decomposition_on_one_gpu(gpu_ctx, world, n_total):
     torch.cuda.synchronize()
     gpu_ctx.row_inv_norms_dev(enc_all.data_ptr(), world * block, L, inv_all.data_ptr())
     gpu_ctx.sync()
+    for r in range(world):                                       # what each rank does before the gather
+        lo, hi, _ = pd.shard_range(n_total, world, r)
+        pd.mask_padding(inv_all[r * block:(r + 1) * block], hi - lo)
+    torch.cuda.synchronize()
     score = pd.device_score_block(gpu_ctx)
     got_idx, got_val = [], []
     for r in range(world):
