@@ -281,18 +281,32 @@ def main():
 
     from pvsim import distributed as pd
     score_block = pd.device_score_block(ctx)
+    ops = pd.DeviceOps(ctx)
+
+    def a2a(out_t, in_t):
+        dist.all_to_all_single(out_t, in_t)
+        torch.cuda.current_stream().synchronize()
+
+    def new_tensor(shape, dtype, fill):
+        t_ = torch.full(shape, fill, dtype=dtype, device=dev)
+        torch.cuda.current_stream().synchronize()      # visible to the context's stream
+        return t_
 
     def step():
         ctx.vlad_encode_dev(cb, desc.data_ptr(), kind, d_off.data_ptr(), n_loc, total_desc, enc_loc.data_ptr(),
                             d_inv_norm=inv_loc.data_ptr())
         if world > 1:
             ctx.sync()                                   # encode (ctx stream) -> collective (torch stream)
-            pd.mask_padding(inv_loc, n_loc)              # padding rows of the last block(s): NaN inverse norm
             dist.all_gather_into_tensor(enc_all, enc_loc)
             dist.all_gather_into_tensor(inv_all, inv_loc)
             torch.cuda.current_stream().synchronize()
-        # score the local query block against the whole gathered corpus (one GEMM + select per rank)
-        pd.retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, N, rank, world, TOPK, score_block, idx, val)
+        if world == 1:
+            pd.retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, N, rank, world, TOPK, score_block, idx, val)
+        else:
+            # every block pair is scored once (dual-store GEMM), k-candidate lists exchanged, merged
+            i_, v_ = pd.retrieve_symmetric(enc_all, inv_all, N, rank, world, TOPK, ops, a2a, new_tensor)
+            idx[:n_loc].copy_(i_)
+            val[:n_loc].copy_(v_)
 
     def barrier():
         if world > 1:
@@ -338,10 +352,12 @@ def main():
         flop_per_launch = 2.0 * 128 * 128 * L * (t128 * (t128 + 1) // 2)      # upper-triangle tiles
     else:
         alg_flop = 2.0 * n_loc * N * L
-        flop_per_launch = 2.0 * 128 * 128 * L * t128 * ((world * per + 127) // 128)
+        # symmetric pair scheme: own block (upper triangle) + (P-1)/2 cross blocks, over several launches per step
+        launches_per_step = max(gemm_n / max(args.steps, 1), 1.0)
+        flop_per_launch = 2.0 * 128 * 128 * L * (t128 * (t128 + 1) / 2 + (world - 1) / 2.0 * t128 * t128) / launches_per_step
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flop_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
-    traffic, traffic_src = pmc_traffic("pvs::gemm_f32_kernel")
+    traffic, traffic_src = pmc_traffic("pvs::gemm_mfma_kernel")
     if world != 1 or N != 8189:
         traffic, traffic_src = None, None             # the committed counters are for the default 1-GPU workload
     stages = {k: {"ms_total": round(v[0], 3), "launches": int(v[1]),
@@ -358,7 +374,7 @@ def main():
                                f" D=128, VLAD K=256 encode + {N}x{N} cosine + top-{TOPK}",
                    "images": N, "descriptors_rank0": total_desc, "descriptor_rows": args.desc,
                    "K": K_CLUSTERS, "D": DIM, "topk": TOPK, "parallelism": f"image-sharded x{world}"},
-        "roofline": {"kernel": "gemm_f32_kernel<128,128> (cosine GEMM: main + split-K tail)", "bound": "mfma", "achieved": round(achieved, 2),
+        "roofline": {"kernel": "gemm_mfma_kernel<128,128,f32> (cosine GEMM: main + split-K tail)", "bound": "mfma", "achieved": round(achieved, 2),
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flop_per_launch,
                      "algorithmic_flop_per_launch": alg_flop,

@@ -135,6 +135,11 @@ int pvs_row_inv_norms_dev(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t 
 int pvs_cosine_dev(pvs_ctx* ctx, const float* d_A, int64_t M, const float* d_B, int64_t N, int64_t L,
                    const float* d_inv_a, const float* d_inv_b, float* d_out, int64_t ldo);
 
+/* Same, and additionally the transposed panel out_t[j*ldt + i] = out[i*ldo + j] (bit-identical): one GEMM then serves
+ * the row queries AND the column queries of a block pair (symmetric multi-GPU scheme, pvsim/distributed.py). */
+int pvs_cosine_dual_dev(pvs_ctx* ctx, const float* d_A, int64_t M, const float* d_B, int64_t N, int64_t L,
+                        const float* d_inv_a, const float* d_inv_b, float* d_out, int64_t ldo, float* d_out_t, int64_t ldt);
+
 /* ---------------------------------------------------------------- top-k: pyvisim/eval.py:37-43,75-80,131-132
  * per query row: np.argsort(-scores)[:k].  Order is (score desc, index asc); NaN scores rank last.
  * pvs_topk_dev consumes a score panel [nq][ncols] (row stride ld) whose column 0 has global index

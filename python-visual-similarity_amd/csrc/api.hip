@@ -525,6 +525,20 @@ PVS_EXPORT int pvs_cosine_dev(pvs_ctx* ctx, const float* d_A, int64_t M, const f
   return launch_cosine_f32(ctx, d_A, M, d_B, N, L, d_inv_a, d_inv_b, d_out, ldo);
 }
 
+PVS_EXPORT int pvs_cosine_dual_dev(pvs_ctx* ctx, const float* d_A, int64_t M, const float* d_B, int64_t N, int64_t L,
+                                   const float* d_inv_a, const float* d_inv_b, float* d_out, int64_t ldo, float* d_out_t,
+                                   int64_t ldt) {
+  PVS_NEED(ctx, "ctx");
+  if (M <= 0 || N <= 0) return PVS_OK;
+  PVS_NEED(d_A, "A");
+  PVS_NEED(d_B, "B");
+  PVS_NEED(d_out, "out");
+  PVS_NEED(d_out_t, "out_t");
+  if (ldo < N || ldt < M) PVS_FAIL(PVS_ERR_INVALID, "cosine dual: ldo < N or ldt < M");
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_cosine_f32_dual(ctx, d_A, M, d_B, N, L, d_inv_a, d_inv_b, d_out, ldo, d_out_t, ldt);
+}
+
 PVS_EXPORT int pvs_cosine(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, int is_f64,
                           void* out) {
   PVS_NEED(ctx, "ctx");

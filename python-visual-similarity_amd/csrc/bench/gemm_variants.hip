@@ -100,7 +100,7 @@ static void run(const char* name, const void* A, const float* inv, int64_t N, in
   int n_main = total, n_tail = 0;
   if (tailk > 1 && total > slots && total % slots) { n_tail = total % slots; n_main = total - n_tail; }
   float* part = nullptr;
-  if (n_tail) CK(hipMalloc(&part, (size_t)n_tail * tailk * BM * BN * 4));
+  if (n_tail) CK(hipMalloc(&part, (size_t)n_tail * (TWO ? (size_t)((L + 1023) / 1024) : (size_t)tailk) * BM * BN * 4));
   auto kf = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_FULL, STAMP, F16, TWO, ILV>;
   auto kp = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_PARTIAL, false, F16, TWO, ILV>;
   auto kr = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_REDUCE, false, F16, TWO, ILV>;
@@ -112,7 +112,7 @@ static void run(const char* name, const void* A, const float* inv, int64_t N, in
     a.tile_base = 0;
     hipLaunchKernelGGL(kf, dim3((unsigned)n_main), dim3(Cfg::THREADS), Cfg::LDS_BYTES, 0, a);
     if (n_tail) {
-      a.tile_base = n_main; a.splitk = tailk; a.partial = part;
+      a.tile_base = n_main; a.splitk = tailk; a.nparts = TWO ? (int)((L + 1023) / 1024) : tailk; a.partial = part;
       hipLaunchKernelGGL(kp, dim3((unsigned)(n_tail * tailk)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, 0, a);
       hipLaunchKernelGGL(kr, dim3((unsigned)n_tail), dim3(Cfg::THREADS), Cfg::LDS_BYTES, 0, a);
     }

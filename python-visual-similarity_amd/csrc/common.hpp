@@ -127,6 +127,8 @@ int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_de
 int launch_row_inv_norms(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L, float* d_inv);
 int launch_cosine_f32(pvs_ctx* ctx, const float* A, int64_t M, const float* B, int64_t N, int64_t L,
                       const float* inva, const float* invb, float* out, int64_t ldo);
+int launch_cosine_f32_dual(pvs_ctx* ctx, const float* A, int64_t M, const float* B, int64_t N, int64_t L, const float* inva,
+                           const float* invb, float* out, int64_t ldo, float* out_t, int64_t ldt);
 int launch_cosine_f16(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
                       const float* invb, float* out, int64_t ldo);
 int launch_f32_to_f16(pvs_ctx* ctx, const float* src, int64_t n, void* dst);

@@ -93,11 +93,13 @@ static int build_plan(pvs_ctx* ctx, int which, int tiles_m, int tiles_n, bool sy
       }
     }
     const int total = (int)t.size();
-    const int rounds = total / slots, rem = total % slots;
+    const int rem = total % slots;
     P.n_main = total;
     P.n_tail = 0;
     P.splitk = 1;
-    if (rounds >= 1 && rem > 0 && rem <= slots / 2) {  // the last round would leave >= half the chip idle
+    if (rem > 0 && rem <= slots / 2) {
+      // the last (or only) round would leave >= half the chip idle: its tiles are split along K over `s` blocks
+      // each (deterministic partial sums + ordered reduce).  Small problems (few queries) run entirely this way.
       int s = 2;
       while (s * 2 <= 16 && rem * s * 2 <= slots) s *= 2;
       P.n_main = total - rem;
@@ -118,16 +120,16 @@ static int build_plan(pvs_ctx* ctx, int which, int tiles_m, int tiles_n, bool sy
   return PVS_OK;
 }
 
-template <bool SYMM, bool F16>
+template <bool SYMM, bool F16, bool DUAL = false>
 static int launch_gemm_mfma(pvs_ctx* ctx, GemmArgs g, const GemmPlan& plan) {
   using Cfg = std::conditional_t<F16, GemmHalf, GemmMain>;
   constexpr int BM = F16 ? 256 : 128, WM = 2, WN = F16 ? 4 : 2;
   // fp16: single-level accumulation (input rounding dominates); LDS-DMA interleaved into the MFMA phase pays only
   // in the general (non-symmetric) order (measured 3.62 vs 3.91 ms; symmetric 2.19 vs 1.98 ms)
   constexpr bool TWO = !F16, ILV = F16 && !SYMM;
-  auto kfull = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_FULL, false, F16, TWO, ILV>;
-  auto kpart = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_PARTIAL, false, F16, TWO, ILV>;
-  auto kred = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_REDUCE, false, F16, TWO, ILV>;
+  auto kfull = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_FULL, false, F16, TWO, ILV, DUAL>;
+  auto kpart = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_PARTIAL, false, F16, TWO, ILV, DUAL>;
+  auto kred = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_REDUCE, false, F16, TWO, ILV, DUAL>;
   static bool attr_set = false;
   if (!attr_set) {
     for (const void* k : {reinterpret_cast<const void*>(kfull), reinterpret_cast<const void*>(kpart),
@@ -140,15 +142,25 @@ static int launch_gemm_mfma(pvs_ctx* ctx, GemmArgs g, const GemmPlan& plan) {
     hipLaunchKernelGGL(kfull, dim3((unsigned)plan.n_main), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
   }
   if (plan.n_tail > 0) {
-    float* part = nullptr;
-    PVS_TRY(ws_reserve(ctx, 4, (size_t)plan.n_tail * plan.splitk * BM * BM * sizeof(float),
-                       reinterpret_cast<void**>(&part)));
-    g.tile_base = plan.n_main;
-    g.splitk = plan.splitk;
-    g.partial = part;
-    hipLaunchKernelGGL(kpart, dim3((unsigned)(plan.n_tail * plan.splitk)), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
-                       ctx->stream, g);
-    hipLaunchKernelGGL(kred, dim3((unsigned)plan.n_tail), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
+    // partial images per tile: one per 1024-k chain (exact fp32 path) or one per slice (fp16 path)
+    const int bk = F16 ? 64 : 32;
+    const int nk = (int)((g.L + bk - 1) / bk);
+    const int nparts = TWO ? (nk + GEMM_KBLOCK / bk - 1) / (GEMM_KBLOCK / bk) : plan.splitk;
+    const size_t bytes = (size_t)plan.n_tail * nparts * BM * BM * sizeof(float);
+    if (bytes > ((size_t)1 << 30)) {
+      // very long rows (e.g. Fisher vectors): the chain images would not fit a sane workspace -> unsplit launch
+      g.tile_base = plan.n_main;
+      hipLaunchKernelGGL(kfull, dim3((unsigned)plan.n_tail), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
+    } else {
+      float* part = nullptr;
+      PVS_TRY(ws_reserve(ctx, 4, bytes, reinterpret_cast<void**>(&part)));
+      g.tile_base = plan.n_main;
+      g.splitk = std::min(plan.splitk, nparts);
+      g.nparts = nparts;
+      g.partial = part;
+      hipLaunchKernelGGL(kpart, dim3((unsigned)(plan.n_tail * g.splitk)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
+      hipLaunchKernelGGL(kred, dim3((unsigned)plan.n_tail), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
+    }
   }
   PVS_HIP(hipGetLastError());
   return PVS_OK;
@@ -157,19 +169,22 @@ static int launch_gemm_mfma(pvs_ctx* ctx, GemmArgs g, const GemmPlan& plan) {
 // shared front end of the two MFMA paths
 template <bool F16>
 static int cosine_mfma(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
-                       const float* invb, float* out, int64_t ldo) {
+                       const float* invb, float* out, int64_t ldo, float* out_t = nullptr, int64_t ldt = 0) {
   constexpr int BT = F16 ? 256 : 128;
   const int tiles_m = (int)((M + BT - 1) / BT), tiles_n = (int)((N + BT - 1) / BT);
   if ((int64_t)tiles_m * tiles_n > 0x3fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "cosine: too many tiles for one launch");
   // self-similarity: same operand, same norms -> only the upper triangle is computed, the rest mirrored
-  const bool symm = (A == B) && (M == N) && (inva == invb);
+  const bool symm = (A == B) && (M == N) && (inva == invb) && out_t == nullptr;
   GemmPlan* plan = nullptr;
   PVS_TRY(build_plan(ctx, F16 ? 1 : 0, tiles_m, tiles_n, symm, ctx->num_cu * (F16 ? 1 : 2), &plan));
   GemmArgs g{};
   g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = L; g.ldb = L; g.inva = inva; g.invb = invb;
-  g.out = out; g.ldo = ldo; g.tiles = plan->d_tiles; g.splitk = 1;
+  g.out = out; g.ldo = ldo; g.out_t = out_t; g.ldt = ldt; g.tiles = plan->d_tiles; g.splitk = 1;
   PVS_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(const_cast<float**>(&g.zero16)), HIP_SYMBOL(g_zero16)));
   if (symm) return launch_gemm_mfma<true, F16>(ctx, g, *plan);
+  if constexpr (!F16) {
+    if (out_t) return launch_gemm_mfma<false, false, true>(ctx, g, *plan);
+  }
   return launch_gemm_mfma<false, F16>(ctx, g, *plan);
 }
 
@@ -286,6 +301,16 @@ int launch_cosine_f32(pvs_ctx* ctx, const float* A, int64_t M, const float* B, i
   }
   PVS_HIP(hipGetLastError());
   return PVS_OK;
+}
+
+int launch_cosine_f32_dual(pvs_ctx* ctx, const float* A, int64_t M, const float* B, int64_t N, int64_t L, const float* inva,
+                           const float* invb, float* out, int64_t ldo, float* out_t, int64_t ldt) {
+  if (M <= 0 || N <= 0) return PVS_OK;
+  if (!((L % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
+        (L <= (int64_t)8 * 1024 * 1024)))
+    PVS_FAIL(PVS_ERR_UNSUPPORTED, "dual-output cosine needs 16-B aligned rows (L %% 4 == 0)");
+  ScopedTimer tm(ctx, T_GEMM);
+  return cosine_mfma<false>(ctx, A, M, B, N, L, inva, invb, out, ldo, out_t, ldt);
 }
 
 int launch_cosine_f64(pvs_ctx* ctx, const double* A, int64_t M, const double* B, int64_t N, int64_t L, double* out) {

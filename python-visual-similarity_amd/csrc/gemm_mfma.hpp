@@ -28,8 +28,10 @@
 //   * tiles come from a host-built list (any order / subset): XCD-aware 8x8 super-tile order for L2 panel sharing;
 //     SYMM (A == B): only tiles tn >= tm are listed, the mirrored tile is written through an LDS transpose
 //     (coalesced) and is bit-identical to the direct one.
-//   * MODE_PARTIAL / MODE_REDUCE: a deterministic split-K for the tiles of the last, partly filled round: S blocks
-//     per tile write raw accumulators, one block per tile sums them in slice order and runs the normal epilogue.
+//   * MODE_PARTIAL / MODE_REDUCE: split-K for the tiles of a partly filled round (and for small problems): S blocks
+//     per tile each run a slice of whole 1024-k chains and store every chain's accumulator; one block per tile adds
+//     the chains in chain order -- the very additions the unsplit kernel makes -- and runs the normal epilogue.
+//     A score therefore does not depend on which tile, launch or split produced it (bitwise).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -53,10 +55,13 @@ struct GemmArgs {
   const float* invb;
   float* out;
   int64_t ldo;
+  float* out_t;      // DUAL: transposed panel out_t[n][m] (row stride ldt); SYMM mirrors into `out` itself
+  int64_t ldt;
   const GemmTile* tiles;  // tile list (device)
   int tile_base;          // first list entry handled by this launch
-  int splitk;             // MODE_PARTIAL / MODE_REDUCE: slices per tile
-  float* partial;         // [tiles in this launch][splitk][BM*BN] raw accumulators
+  int splitk;             // MODE_PARTIAL: blocks (k-slices) per tile
+  int nparts;             // partial images per tile: TWO ? number of 1024-k chains : splitk
+  float* partial;         // [tiles in this launch][nparts][BM*BN] raw accumulators
   const float* zero16;    // 16 B of zeros in device memory (source for k-chunks past L)
   unsigned long long* stamps;  // diagnostic builds only (STAMP)
 };
@@ -195,13 +200,16 @@ struct GemmLoader {
 // OCC = minimum waves per SIMD the register allocator must leave room for (blocks per CU * threads / 256)
 // TWO = two-level accumulation (needed for fp32-grade sums; off for the fp16 path, whose input rounding dominates)
 // ILV = spread the next tile's LDS-DMA issue over the four k-steps of the current tile instead of one burst
+// DUAL = besides out[m][n] also write the transposed panel out_t[n][m] (every tile), so that one GEMM serves the
+//        row queries AND the column queries of a block pair (multi-GPU symmetric scheme).
 template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, int MODE = GEMM_MODE_FULL, bool STAMP = false,
-          bool F16 = false, bool TWO = true, bool ILV = false>
+          bool F16 = false, bool TWO = true, bool ILV = false, bool DUAL = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g) {
   using Cfg = GemmCfg<BM, BN, WM, WN, STAGES, F16>;
   constexpr int GEMM_BK = Cfg::BK;
   constexpr int MI = Cfg::MI, NI = Cfg::NI;
-  static_assert(!SYMM || BM == BN, "the mirrored store needs square tiles");
+  static_assert(!(SYMM || DUAL) || BM == BN, "the mirrored store needs square tiles");
+  static_assert(!(SYMM && DUAL), "SYMM already mirrors");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: LDS-DMA bases stay in SGPRs
@@ -249,9 +257,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
     }
 
     const int nk_all = (int)((g.L + GEMM_BK - 1) / GEMM_BK);
+    constexpr int CHAIN_KT = GEMM_KBLOCK / GEMM_BK;  // k-tiles per accumulation chain
     int kt0 = 0, kt1 = nk_all;
     if constexpr (MODE == GEMM_MODE_PARTIAL) {
-      const int per = (nk_all + g.splitk - 1) / g.splitk;
+      // slices hold whole chains (TWO) so that the reduce can replay the unsplit kernel's additions exactly
+      const int unit = TWO ? CHAIN_KT : 1;
+      const int units = (nk_all + unit - 1) / unit;
+      const int per = ((units + g.splitk - 1) / g.splitk) * unit;
       kt0 = min(nk_all, slice * per);
       kt1 = min(nk_all, kt0 + per);
     }
@@ -350,15 +362,28 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
         seg[0] += s1 - s0; seg[1] += s2 - s1; seg[2] += s3 - s2; seg[3] += s4 - s3;
       }
       if constexpr (TWO) {
-        if (((kt - kt0) & (GEMM_KBLOCK / GEMM_BK - 1)) == GEMM_KBLOCK / GEMM_BK - 1) {
+        if ((kt & (CHAIN_KT - 1)) == CHAIN_KT - 1 || (MODE == GEMM_MODE_PARTIAL && kt == kt1 - 1)) {  // chain complete
+          if constexpr (MODE == GEMM_MODE_PARTIAL) {
+            float* dst = g.partial + ((int64_t)lin * g.nparts + kt / CHAIN_KT) * (BM * BN) + wave * (MI * NI * 1024);
 #pragma unroll
-          for (int a = 0; a < MI; ++a)
+            for (int a = 0; a < MI; ++a)
 #pragma unroll
-            for (int b = 0; b < NI; ++b) {
-              tot[a][b] += acc[a][b];
+              for (int b = 0; b < NI; ++b)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-            }
+                for (int r = 0; r < 16; ++r) {
+                  dst[(a * NI + b) * 1024 + r * 64 + lane] = acc[a][b][r];
+                  acc[a][b][r] = 0.f;
+                }
+          } else {
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+              for (int b = 0; b < NI; ++b) {
+                tot[a][b] += acc[a][b];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+              }
+          }
         }
       }
     }
@@ -381,19 +406,21 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
   // raw accumulator image of a block: [wave][a*NI+b][reg][lane]  (256-B coalesced rows)
   constexpr int PART_ELEMS = BM * BN;
   if constexpr (MODE == GEMM_MODE_PARTIAL) {
-    float* dst = g.partial + ((int64_t)lin * g.splitk + slice) * PART_ELEMS + wave * (MI * NI * 1024);
+    if constexpr (!TWO) {  // single-level accumulation: one image per slice
+      float* dst = g.partial + ((int64_t)lin * g.nparts + slice) * PART_ELEMS + wave * (MI * NI * 1024);
 #pragma unroll
-    for (int a = 0; a < MI; ++a)
+      for (int a = 0; a < MI; ++a)
 #pragma unroll
-      for (int b = 0; b < NI; ++b)
+        for (int b = 0; b < NI; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[(a * NI + b) * 1024 + r * 64 + lane] = acc[a][b][r];
+          for (int r = 0; r < 16; ++r) dst[(a * NI + b) * 1024 + r * 64 + lane] = acc[a][b][r];
+    }
     return;
   }
   if constexpr (MODE == GEMM_MODE_REDUCE) {
-    // slices are added in index order: deterministic, independent of how the partial launch was scheduled
-    for (int s = 0; s < g.splitk; ++s) {
-      const float* src = g.partial + ((int64_t)lin * g.splitk + s) * PART_ELEMS + wave * (MI * NI * 1024);
+    // images are added in index order: with TWO these are the chain sums, added exactly as the unsplit kernel does
+    for (int s = 0; s < g.nparts; ++s) {
+      const float* src = g.partial + ((int64_t)lin * g.nparts + s) * PART_ELEMS + wave * (MI * NI * 1024);
 #pragma unroll
       for (int a = 0; a < MI; ++a)
 #pragma unroll
@@ -419,9 +446,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
       }
     }
   }
-  if constexpr (SYMM) {
-    if (tm != tn) {
-      // mirrored tile out[n][m]: transpose each 32x32 sub-tile through this wave's private LDS patch
+  if constexpr (SYMM || DUAL) {
+    if (DUAL || tm != tn) {
+      // mirrored tile: transpose each 32x32 sub-tile through this wave's private LDS patch, coalesced rows out
+      float* const dst = DUAL ? g.out_t : g.out;
+      const int64_t ldd = DUAL ? g.ldt : g.ldo;
       __syncthreads();  // every wave is done reading the operand stages
       float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 33);
 #pragma unroll
@@ -435,7 +464,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
           for (int rr = 0; rr < 16; ++rr) {
             const int nn = 2 * rr + h;           // row of the mirrored tile handled by this half-wave
             const float v = patch[nn * 33 + i];  // lanes i -> consecutive m (LDS ops of one wave execute in order)
-            if (nb + nn < g.N && mb + i < g.M) g.out[(nb + nn) * g.ldo + mb + i] = v;
+            if (nb + nn < g.N && mb + i < g.M) dst[(nb + nn) * ldd + mb + i] = v;
           }
         }
       }

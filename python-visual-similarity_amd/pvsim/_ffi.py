@@ -62,6 +62,7 @@ SIGNATURES = {
     "pvs_cosine": [_vp, _vp, _i64, _vp, _i64, _i64, _int, _vp],
     "pvs_row_inv_norms_dev": [_vp, _vp, _i64, _i64, _vp],
     "pvs_cosine_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64],
+    "pvs_cosine_dual_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64],
     "pvs_topk_dev": [_vp, _vp, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp],
     "pvs_cosine_topk_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _i64, _int, _vp, _vp],
     "pvs_f32_to_f16_dev": [_vp, _vp, _i64, _vp],

@@ -17,7 +17,8 @@ from typing import Callable
 
 import numpy as np
 
-__all__ = ["shard_range", "gather_blocks", "mask_padding", "retrieve_sharded", "device_score_block", "ShardedVLADIndex"]
+__all__ = ["shard_range", "gather_blocks", "mask_padding", "retrieve_sharded", "device_score_block",
+           "retrieve_symmetric", "symmetric_local", "symmetric_finish", "DeviceOps", "ShardedVLADIndex"]
 
 
 def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int, int]:
@@ -74,6 +75,151 @@ def device_score_block(ctx):
                             k, col_offset, merge, idx.data_ptr(), val.data_ptr())
 
     return score
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Symmetric all-vs-all retrieval: cos(a, b) = cos(b, a), so every unordered block pair is scored ONCE, by one of its
+# two ranks, with a GEMM that stores the panel AND its transpose (pvs_cosine_dual_dev).  The row-wise top-k of the
+# panel serves the computing rank's queries, the row-wise top-k of the transposed panel serves the partner's
+# queries and is shipped to it in one all-to-all of k-candidate lists (B*k*12 bytes per pair); every rank finally
+# merges the lists it computed with the lists it received (pvs_topk_merge_dev).
+#
+#   rank r scores   (r, r)                  symmetric kernel (upper-triangle tiles, mirrored)
+#                   (r, r+1 .. r+h)         h = (P-1)//2 full blocks, dual store, in ONE launch (two on wrap-around)
+#                   (r, r+P/2)  if P even   half of that block: the lower rank takes the partner's rows [0, B/2),
+#                                           the higher rank the lower rank's rows [B/2, B) -- see _half_split
+#   => N^2 / (2P) scores per rank instead of N^2 / P.
+# Results are bit-identical to the single-GPU path: a score does not depend on which tile, launch or K-split produced
+# it (csrc/gemm_mfma.hpp), the transposed store copies the same fp32 value, and all lists are ordered
+# (score desc, index asc).
+class DeviceOps:
+    """The four device operations of the scheme, bound to a pvsim.Context (tests plug in CPU stand-ins)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def sym_topk(self, q, n, inv, k, col_offset, idx, val):
+        self.ctx.cosine_topk_dev(q.data_ptr(), n, q.data_ptr(), n, q.shape[1], inv.data_ptr(), inv.data_ptr(), k,
+                                 col_offset, False, idx.data_ptr(), val.data_ptr())
+
+    def dual(self, a, m, b, n, inv_a, inv_b, panel, panel_t):
+        self.ctx.cosine_dual_dev(a.data_ptr(), m, b.data_ptr(), n, a.shape[1], inv_a.data_ptr(), inv_b.data_ptr(),
+                                 panel.data_ptr(), n, panel_t.data_ptr(), m)
+
+    def topk(self, scores, nq, ncols, k, col_offset, merge, idx, val):
+        self.ctx.topk_dev(scores.data_ptr(), nq, ncols, ncols, k, col_offset, merge, idx.data_ptr(), val.data_ptr())
+
+    def merge(self, idx_lists, val_lists, n_lists, nq, k, idx, val):
+        self.ctx.topk_merge_dev(idx_lists.data_ptr(), val_lists.data_ptr(), n_lists, nq, k, idx.data_ptr(), val.data_ptr())
+
+    def sync(self):
+        self.ctx.sync()
+
+
+def _rows(n_total, world, r):
+    lo, hi, _ = shard_range(n_total, world, r)
+    return hi - lo
+
+
+def retrieve_symmetric(enc_all, inv_all, n_total: int, rank: int, world: int, k: int, ops, all_to_all, new_tensor):
+    """Top-k of this rank's queries against the whole corpus, scoring each block pair once (see above).
+
+    enc_all (world*B, L) / inv_all (world*B,): the gathered encodings and inverse norms (padding rows unused).
+    ops: DeviceOps-like.  all_to_all(out, inp): exchange of equal (B*k)-element slabs between ranks, e.g.
+    torch.distributed.all_to_all_single.  new_tensor(shape, dtype, fill): allocator on the right device.
+    Returns (idx (n_loc, k) int64, val (n_loc, k) float32)."""
+    st = symmetric_local(enc_all, inv_all, n_total, rank, world, k, ops, new_tensor)
+    all_to_all(st["m_idx"][:world].reshape(-1), st["s_idx"].reshape(-1))
+    all_to_all(st["m_val"][:world].reshape(-1), st["s_val"].reshape(-1))
+    return symmetric_finish(st, ops, new_tensor)
+
+
+def symmetric_local(enc_all, inv_all, n_total: int, rank: int, world: int, k: int, ops, new_tensor) -> dict:
+    """Phase 1 (no communication): score this rank's block pairs; returns the send / merge buffers."""
+    import torch
+    lo, hi, B = shard_range(n_total, world, rank)
+    n_r = hi - lo
+    P = world
+    # slot p < P: list computed by rank p for my queries (received); slot P: what I computed for myself
+    m_idx = new_tensor((P + 1, B, k), torch.int64, -1)
+    m_val = new_tensor((P + 1, B, k), torch.float32, float("-inf"))
+    s_idx = new_tensor((P, B, k), torch.int64, -1)           # slot p: list I computed for rank p's queries
+    s_val = new_tensor((P, B, k), torch.float32, float("-inf"))
+    own_i, own_v = m_idx[P], m_val[P]
+    blk = lambda t, r: t[r * B:(r + 1) * B]                  # noqa: E731
+
+    if n_r > 0:
+        # ---- (r, r): symmetric kernel
+        ops.sym_topk(blk(enc_all, rank), n_r, blk(inv_all, rank), k, rank * B, own_i, own_v)
+        # ---- (r, r+1 .. r+h): full blocks, dual store; contiguous runs of blocks go in one launch
+        h = (P - 1) // 2
+        # contiguous runs of partner blocks (one launch each): a run ends at the wrap-around, after a short block
+        # (only the last non-empty block of the corpus can be short) and skips empty blocks
+        runs, cur = [], None
+        for j in range(1, h + 1):
+            s_ = (rank + j) % P
+            n_s = _rows(n_total, P, s_)
+            if n_s == 0 or (cur is not None and s_ != cur[0] + cur[1]):
+                if cur is not None:
+                    runs.append(tuple(cur))
+                    cur = None
+                if n_s == 0:
+                    continue
+            if cur is None:
+                cur = [s_, 0]
+            cur[1] += 1
+            if n_s < B:
+                runs.append(tuple(cur))
+                cur = None
+        if cur is not None:
+            runs.append(tuple(cur))
+        for s0, length in runs:
+            n_cols = sum(_rows(n_total, P, s0 + t) for t in range(length))
+            if n_cols == 0:
+                continue
+            # blocks s0 .. s0+length-1 are contiguous in enc_all; only the LAST rank's block can be short, and a
+            # short block inside a run would leave a gap -- runs therefore never extend past a short block
+            span = (length - 1) * B + _rows(n_total, P, s0 + length - 1)
+            assert span == n_cols, "a short block may only end a run"
+            panel = new_tensor((n_r, span), torch.float32, 0.0)
+            panel_t = new_tensor((span, n_r), torch.float32, 0.0)
+            ops.dual(blk(enc_all, rank), n_r, enc_all[s0 * B:], span, blk(inv_all, rank), inv_all[s0 * B:], panel, panel_t)
+            ops.topk(panel, n_r, span, k, s0 * B, True, own_i, own_v)                       # my queries
+            for t in range(length):                                                         # partners' queries
+                s, n_s = s0 + t, _rows(n_total, P, s0 + t)
+                if n_s > 0:
+                    ops.topk(panel_t[t * B:], n_s, n_r, k, rank * B, False, s_idx[s], s_val[s])
+        # ---- (r, r + P/2) for even P: the block pair is split between its two ranks
+        if P % 2 == 0:
+            partner = (rank + P // 2) % P
+            a, b = min(rank, partner), max(rank, partner)    # panel = Q_a x DB_b^T; a takes b's rows [0, hb), b the rest
+            n_a, n_b = _rows(n_total, P, a), _rows(n_total, P, b)
+            hb = min(n_b, (B + 1) // 2)
+            c0, c1 = (0, hb) if rank == a else (hb, n_b)     # columns of the panel (= rows of block b) I compute
+            if n_a > 0 and c1 > c0:
+                w = c1 - c0
+                panel = new_tensor((n_a, w), torch.float32, 0.0)
+                panel_t = new_tensor((w, n_a), torch.float32, 0.0)
+                ops.dual(blk(enc_all, a), n_a, enc_all[b * B + c0:], w, blk(inv_all, a), inv_all[b * B + c0:], panel, panel_t)
+                if rank == a:
+                    ops.topk(panel, n_a, w, k, b * B + c0, True, own_i, own_v)              # my queries vs b[0:hb)
+                    ops.topk(panel_t, w, n_a, k, a * B, False, s_idx[b][c0:], s_val[b][c0:])   # b's queries [0:hb) vs me
+                else:
+                    ops.topk(panel, n_a, w, k, b * B + c0, False, s_idx[a], s_val[a])       # a's queries vs my rows [hb:)
+                    ops.topk(panel_t, w, n_a, k, a * B, True, own_i[c0:], own_v[c0:])       # my queries [hb:) vs a
+    ops.sync()
+    return {"m_idx": m_idx, "m_val": m_val, "s_idx": s_idx, "s_val": s_val, "n_r": n_r, "B": B, "k": k, "P": P}
+
+
+def symmetric_finish(st: dict, ops, new_tensor):
+    """Phase 2 (after the all-to-all filled m_idx[:P] / m_val[:P]): merge the P received lists with the own list."""
+    import torch
+    out_i = new_tensor((st["B"], st["k"]), torch.int64, -1)
+    out_v = new_tensor((st["B"], st["k"]), torch.float32, float("-inf"))
+    if st["n_r"] > 0:
+        ops.merge(st["m_idx"], st["m_val"], st["P"] + 1, st["B"], st["k"], out_i, out_v)
+        ops.sync()
+    return out_i[:st["n_r"]], out_v[:st["n_r"]]
 
 
 class ShardedVLADIndex:

@@ -239,6 +239,10 @@ class Context:
     def cosine_dev(self, d_a, M, d_b, N, L, d_inva, d_invb, d_out, ldo):
         check(_ffi.lib().pvs_cosine_dev(self.handle, ptr(d_a), M, ptr(d_b), N, L, ptr(d_inva), ptr(d_invb), ptr(d_out), ldo))
 
+    def cosine_dual_dev(self, d_a, M, d_b, N, L, d_inva, d_invb, d_out, ldo, d_out_t, ldt):
+        check(_ffi.lib().pvs_cosine_dual_dev(self.handle, ptr(d_a), M, ptr(d_b), N, L, ptr(d_inva), ptr(d_invb), ptr(d_out),
+                                             ldo, ptr(d_out_t), ldt))
+
     def topk_dev(self, d_scores, nq, ncols, ld, k, col_offset, merge, d_idx, d_val):
         check(_ffi.lib().pvs_topk_dev(self.handle, ptr(d_scores), nq, ncols, ld, k, col_offset, int(merge), ptr(d_idx),
                                       ptr(d_val)))

@@ -83,3 +83,82 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(hi - lo <= blk for lo, hi, blk in spans)
+
+
+# ----------------------------------------------------------------------------------------- symmetric pair scheme
+class _CpuOps:
+    """CPU stand-ins (NumPy / oracle) for pvsim.distributed.DeviceOps -- same call contract."""
+
+    @staticmethod
+    def _select(scores, cand_idx, k, merge, idx, val):
+        n_q = scores.shape[0]
+        ci, cv = cand_idx, scores
+        if merge:
+            keep = idx[:n_q].numpy() >= 0
+            ci = np.concatenate([np.where(keep, idx[:n_q].numpy(), -1), ci], axis=1)
+            cv = np.concatenate([np.where(keep, val[:n_q].numpy(), -np.inf), cv], axis=1)
+        order = np.lexsort((ci, -cv), axis=1)[:, :k]
+        ti, tv = np.take_along_axis(ci, order, 1), np.take_along_axis(cv, order, 1).astype(np.float32)
+        ti = np.where(np.isneginf(tv), -1, ti)
+        idx[:n_q, :ti.shape[1]] = torch.from_numpy(ti)
+        val[:n_q, :tv.shape[1]] = torch.from_numpy(tv)
+
+    def sym_topk(self, q, n, inv, k, col_offset, idx, val):
+        import pvsim_oracle as orc
+        s = orc.cosine_similarity(q[:n].numpy(), q[:n].numpy())
+        self._select(s, np.tile(np.arange(col_offset, col_offset + n), (n, 1)), k, False, idx, val)
+
+    def dual(self, a, m, b, n, inv_a, inv_b, panel, panel_t):
+        import pvsim_oracle as orc
+        s = orc.cosine_similarity(a[:m].numpy(), b[:n].numpy())
+        panel[:m, :n] = torch.from_numpy(s)
+        panel_t[:n, :m] = torch.from_numpy(np.ascontiguousarray(s.T))
+
+    def topk(self, scores, nq, ncols, k, col_offset, merge, idx, val):
+        s = scores.reshape(-1)[: nq * ncols].reshape(nq, ncols).numpy()
+        self._select(s, np.tile(np.arange(col_offset, col_offset + ncols), (nq, 1)), k, merge, idx, val)
+
+    def merge(self, idx_lists, val_lists, n_lists, nq, k, idx, val):
+        ci = idx_lists.numpy().transpose(1, 0, 2).reshape(nq, n_lists * k)
+        cv = np.where(ci >= 0, val_lists.numpy().transpose(1, 0, 2).reshape(nq, n_lists * k), -np.inf)
+        self._select(cv, ci, k, False, idx, val)
+
+    def sync(self):
+        pass
+
+
+def _sym_worker(rank, world, port, n_total, k, out_dir):
+    for p in (os.path.join(REPO, "python-visual-similarity_amd"), os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+        sys.path.insert(0, p)
+    from pvsim import distributed as pd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(321)
+    enc = rng.normal(size=(n_total, 40)).astype(np.float32)
+    lo, hi, block = pd.shard_range(n_total, world, rank)
+    enc_loc = torch.zeros((block, 40), dtype=torch.float32)
+    enc_loc[: hi - lo] = torch.from_numpy(enc[lo:hi])
+    inv_loc = torch.ones((block,), dtype=torch.float32)
+    enc_all, inv_all = pd.gather_blocks(enc_loc, inv_loc)             # real all_gather_into_tensor
+    idx, val = pd.retrieve_symmetric(enc_all, inv_all, n_total, rank, world, k, _CpuOps(),
+                                     lambda o, i: dist.all_to_all_single(o, i),   # real all-to-all
+                                     lambda shape, dtype, fill: torch.full(shape, fill, dtype=dtype))
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), idx=idx.numpy(), val=val.numpy(), enc=enc)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 21), (3, 20), (4, 30)])
+def test_symmetric_pair_scheme_gloo(tmp_path, world, n_total):
+    """The symmetric block-pair scheme with REAL collectives (gloo all-gather + all-to-all) and CPU stand-in kernels:
+    every pair scored once, lists exchanged, merged -> equals the single-process ranking."""
+    import pvsim_oracle as orc
+    k = 4
+    port = 29900 + (os.getpid() % 1500) + world * 7 + n_total
+    mp.spawn(_sym_worker, args=(world, port, n_total, k, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"s{r}.npz") for r in range(world)]
+    enc = parts[0]["enc"]
+    ridx, rval = orc.topk(orc.cosine_similarity(enc, enc), k)
+    assert np.array_equal(np.concatenate([p["idx"] for p in parts]), ridx)
+    np.testing.assert_allclose(np.concatenate([p["val"] for p in parts]), rval, atol=1e-6)

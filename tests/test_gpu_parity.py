@@ -408,3 +408,46 @@ def test_fp16_cosine_and_recall(gpu_ctx, tables):
     recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(i16, idx32)])
     print(f"fp16 recall@{k} vs fp32: {recall:.4f}")
     assert recall >= 0.99 and np.array_equal(i16[:, 0], np.arange(n))
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 700), (3, 1000), (4, 1030), (8, 2047), (8, 1800), (5, 513)])
+def test_symmetric_pair_scheme_on_one_gpu(gpu_ctx, world, n_total):
+    """pvsim.distributed.retrieve_symmetric, all ranks run one after the other on ONE GPU with the all-to-all emulated
+    by routing the send slabs: every block pair scored once (dual-store GEMM), lists exchanged and merged.  Must be
+    BIT-identical (indices and values) to the single-GPU ranking, including uneven / empty trailing blocks."""
+    import torch
+    from pvsim import distributed as pd
+    rng = np.random.default_rng(world * 1000 + n_total)
+    L, k = 256, 7
+    enc = rng.normal(size=(n_total, L)).astype(np.float32)
+    enc[n_total // 2] = enc[5]                                   # a tie between different blocks
+    ref_idx, ref_val = gpu_ctx.cosine_topk(enc, enc, k)
+    dev = torch.device("cuda", 0)
+    _, _, B = pd.shard_range(n_total, world, 0)
+    enc_all = torch.zeros((world * B, L), dtype=torch.float32, device=dev)
+    inv_all = torch.ones((world * B,), dtype=torch.float32, device=dev)
+    for r in range(world):
+        lo, hi, _ = pd.shard_range(n_total, world, r)
+        enc_all[r * B: r * B + hi - lo] = torch.from_numpy(enc[lo:hi]).to(dev)
+    torch.cuda.synchronize()
+    gpu_ctx.row_inv_norms_dev(enc_all.data_ptr(), world * B, L, inv_all.data_ptr())
+    gpu_ctx.sync()
+    ops = pd.DeviceOps(gpu_ctx)
+
+    def new_tensor(shape, dtype, fill):
+        t_ = torch.full(shape, fill, dtype=dtype, device=dev)
+        torch.cuda.synchronize()
+        return t_
+
+    states = [pd.symmetric_local(enc_all, inv_all, n_total, r, world, k, ops, new_tensor) for r in range(world)]
+    for r in range(world):                                       # all_to_all: slab p of rank r <- slab r of rank p
+        for p in range(world):
+            states[r]["m_idx"][p].copy_(states[p]["s_idx"][r])
+            states[r]["m_val"][p].copy_(states[p]["s_val"][r])
+    torch.cuda.synchronize()
+    got_i, got_v = [], []
+    for r in range(world):
+        i_, v_ = pd.symmetric_finish(states[r], ops, new_tensor)
+        got_i.append(i_.cpu().numpy()); got_v.append(v_.cpu().numpy())
+    assert np.array_equal(np.concatenate(got_i), ref_idx)
+    assert np.array_equal(np.concatenate(got_v), ref_val)
