@@ -84,10 +84,10 @@ static std::vector<GemmTile> tile_list(int tm_n, int tn_n, bool symm) {
 
 // TAILK > 1: the tiles of the last partial round (slots = 512) go through the split-K tail
 template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, bool STAMP = false, bool F16 = false,
-          bool TWO = true, bool ILV = false>
+          bool TWO = true, bool ILV = false, int LW = WM * WN>
 static void run(const char* name, const void* A, const float* inv, int64_t N, int64_t L, float* out, int ns,
                 const double* ref_h, const int* sm_h, const int* sn_h, int tailk) {
-  using Cfg = GemmCfg<BM, BN, WM, WN, STAGES, F16>;
+  using Cfg = GemmCfg<BM, BN, WM, WN, STAGES, F16, LW>;
   GemmArgs g{};
   g.A = A; g.B = A; g.M = N; g.N = N; g.L = L; g.lda = g_ld; g.ldb = g_ld; g.inva = inv; g.invb = inv; g.out = out;
   g.ldo = N; g.splitk = 1;
@@ -101,9 +101,9 @@ static void run(const char* name, const void* A, const float* inv, int64_t N, in
   if (tailk > 1 && total > slots && total % slots) { n_tail = total % slots; n_main = total - n_tail; }
   float* part = nullptr;
   if (n_tail) CK(hipMalloc(&part, (size_t)n_tail * (TWO ? (size_t)((L + 1023) / 1024) : (size_t)tailk) * BM * BN * 4));
-  auto kf = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_FULL, STAMP, F16, TWO, ILV>;
-  auto kp = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_PARTIAL, false, F16, TWO, ILV>;
-  auto kr = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_REDUCE, false, F16, TWO, ILV>;
+  auto kf = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_FULL, STAMP, F16, TWO, ILV, false, LW>;
+  auto kp = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_PARTIAL, false, F16, TWO, ILV, false, LW>;
+  auto kr = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_REDUCE, false, F16, TWO, ILV, false, LW>;
   for (const void* k : {(const void*)kf, (const void*)kp, (const void*)kr})
     CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
   if (STAMP) CK(hipMalloc(&g.stamps, (size_t)n_main * 64));
@@ -197,6 +197,10 @@ int main(int argc, char** argv) {
     std::vector<double> refh(ns);
     CK(hipMemcpy(refh.data(), d_ref, ns * 8, hipMemcpyDeviceToHost));
     RUNH(256, 256, 2, 4, 2, false, 2, false, 1);
+    run<256, 256, 2, 4, 2, false, 2, false, true, false, false, 4>("f16 256x256 LW4", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
+    run<256, 256, 2, 4, 2, false, 2, true, true, false, false, 4>("f16 256x256 LW4 stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
+    run<256, 256, 2, 4, 2, true, 2, false, true, false, false, 4>("f16 256x256 LW4 symm", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 8);
+    run<256, 256, 2, 4, 2, false, 2, false, true, false, true, 4>("f16 256x256 LW4 ilv", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
     RUNH(256, 256, 2, 4, 2, false, 2, true, 1);
     run<256, 256, 2, 4, 2, false, 2, true, true, false, false>("f16 256x256 stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
     RUNH(128, 128, 2, 2, 2, false, 2, false, 1);

@@ -72,7 +72,8 @@ enum { GEMM_MODE_FULL = 0, GEMM_MODE_PARTIAL = 1, GEMM_MODE_REDUCE = 2 };
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool F16 = false>
+// LW = number of waves that issue the LDS-DMA loads (the first LW waves of the workgroup); the others only compute
+template <int BM, int BN, int WM, int WN, int STAGES, bool F16 = false, int LW = WM * WN>
 struct GemmCfg {
   static constexpr int ESZ = F16 ? 2 : 4;
   static constexpr int BK = GEMM_ROW_BYTES / ESZ;  // k-values per k-tile: 32 floats or 64 halfs
@@ -82,10 +83,11 @@ struct GemmCfg {
   static constexpr int A_BYTES = BM * GEMM_ROW_BYTES, B_BYTES = BN * GEMM_ROW_BYTES;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;            // wave-instructions per tile
-  static constexpr int LOADS_PER_WAVE = (A_INSTR + B_INSTR) / WAVES;  // per k-tile
+  static constexpr int LOADER_WAVES = LW;
+  static constexpr int LOADS_PER_WAVE = (A_INSTR + B_INSTR) / LW;  // per k-tile, per loader wave
   static constexpr int MIRROR_BYTES = WAVES * 32 * 33 * 4;
   static constexpr int LDS_BYTES = STAGES * STAGE_BYTES > MIRROR_BYTES ? STAGES * STAGE_BYTES : MIRROR_BYTES;
-  static_assert((A_INSTR + B_INSTR) % WAVES == 0, "tile loads must divide evenly over the waves");
+  static_assert((A_INSTR + B_INSTR) % LW == 0, "tile loads must divide evenly over the loader waves");
   static_assert(A_INSTR % LOADS_PER_WAVE == 0, "a wave's loads must not straddle the A / B boundary");
   static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "wave tile must be a multiple of 32x32");
 };
@@ -203,9 +205,9 @@ struct GemmLoader {
 // DUAL = besides out[m][n] also write the transposed panel out_t[n][m] (every tile), so that one GEMM serves the
 //        row queries AND the column queries of a block pair (multi-GPU symmetric scheme).
 template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, int MODE = GEMM_MODE_FULL, bool STAMP = false,
-          bool F16 = false, bool TWO = true, bool ILV = false, bool DUAL = false>
+          bool F16 = false, bool TWO = true, bool ILV = false, bool DUAL = false, int LW = WM * WN>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g) {
-  using Cfg = GemmCfg<BM, BN, WM, WN, STAGES, F16>;
+  using Cfg = GemmCfg<BM, BN, WM, WN, STAGES, F16, LW>;
   constexpr int GEMM_BK = Cfg::BK;
   constexpr int MI = Cfg::MI, NI = Cfg::NI;
   static_assert(!(SYMM || DUAL) || BM == BN, "the mirrored store needs square tiles");
@@ -269,8 +271,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
     }
     const bool ktail = (g.L % GEMM_BK) != 0;  // only the last k-tile can reach past L
     GemmLoader<Cfg> ld;
-    ld.init(g, m0, n0, wave, lane);
+    const bool loader = wave < Cfg::LOADER_WAVES;  // wave-uniform
+    if (loader) ld.init(g, m0, n0, wave, lane);
     auto stage_tile = [&](int t) {
+      if (!loader) return;
       char* st = smem + ((t - kt0) % STAGES) * Cfg::STAGE_BYTES;
       if (ktail && t == nk_all - 1) ld.issue_checked(g, (int64_t)t * GEMM_BK, st);
       else ld.template issue<0, Cfg::LOADS_PER_WAVE>((int64_t)t * GEMM_BK, st);
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
           for (int b = 0; b < NI; ++b) ds_read_frag(bv[n][b], base + offb[b][t + 1]);
         }
         if constexpr (ILV) {
-          if (inl) {
+          if (inl && loader) {
             constexpr int QN = Cfg::LOADS_PER_WAVE;
             char* st = smem + ((tnext - kt0) % STAGES) * Cfg::STAGE_BYTES;
             const int64_t k0n = (int64_t)tnext * GEMM_BK;

@@ -451,3 +451,32 @@ def test_symmetric_pair_scheme_on_one_gpu(gpu_ctx, world, n_total):
         got_i.append(i_.cpu().numpy()); got_v.append(v_.cpu().numpy())
     assert np.array_equal(np.concatenate(got_i), ref_idx)
     assert np.array_equal(np.concatenate(got_v), ref_val)
+
+
+# ======================================================================================= deep features (config 3 front end)
+def test_deep_conv_feature_extractor_and_fisher_end_to_end():
+    """DeepConvFeature on PyTorch-ROCm (own VGG16 `features` stack, random weights: no checkpoint offline): hook on the
+    last Conv2d (pre-ReLU), 224x224 -> 14x14 = 196 descriptors of 512 (+2 spatial) dims, batch == per-image; then the
+    drop-in FisherVectorEncoder on those descriptors equals the CPU restatement of the reference."""
+    import torch
+    from pvsim.features import DeepConvFeature
+    from pvsim.encoders import FisherVectorEncoder
+    from pvsim.models import GMMModel
+    torch.manual_seed(0)
+    fx = DeepConvFeature(spatial_encoding=True, device="cuda")
+    assert fx.output_dim == 514 and fx.selected_layer_name.endswith("28")
+    rng = np.random.default_rng(1)
+    imgs = [rng.integers(0, 256, size=(96 + 16 * i, 120, 3), dtype=np.uint8) for i in range(3)]
+    d0 = fx(imgs[0])
+    assert d0.shape == (196, 514) and d0.dtype == np.float32
+    np.testing.assert_allclose(d0[:, 512], np.tile(np.arange(14) / 14, 14), atol=1e-7)      # x / W
+    np.testing.assert_allclose(d0[:, 513], np.repeat(np.arange(14) / 14, 14), atol=1e-7)    # y / H
+    batch = fx.batch(imgs).cpu().numpy()
+    np.testing.assert_allclose(batch[0], d0, atol=1e-4)          # conv algorithms may differ between batch sizes
+    K, D = 8, 514
+    gm = GMMModel(np.full(K, 1.0 / K), rng.normal(0, 0.05, (K, D)), rng.uniform(0.01, 0.05, (K, D)))
+    enc = FisherVectorEncoder(fx, gmm_model=gm)
+    f = enc.encode(imgs)
+    assert f.shape == (3, K + 2 * K * D) and f.dtype == np.float64
+    ref = orc.fisher_encode([fx(im) for im in imgs], gm.weights_, gm.means_, gm.covariances_)
+    np.testing.assert_allclose(f, ref, rtol=0, atol=1e-7)        # extractor output re-computed per call (conv noise)

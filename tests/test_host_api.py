@@ -203,3 +203,18 @@ def test_eval_bookkeeping_against_golden(monkeypatch, tables):
         assert abs(ev.top_k_map(imgs, labels, emap, plab, FakeEncoder(), k) - float(g[key])) < 1e-12
     top = ev.retrieve_top_k_similar(imgs[0], emap, FakeEncoder(), k=7)
     assert [paths.index(p) for p, _ in top] == list(g["top7_index"][0])
+
+
+def test_index_persistence_roundtrip(tmp_path):
+    from pvsim import index
+    rng = np.random.default_rng(0)
+    emap = {f"b/{i}.jpg": rng.random(6).astype(np.float32) for i in (3, 1, 2)}
+    p = str(tmp_path / "idx.npz")
+    index.save_encoding_map(p, emap)
+    back = index.load_encoding_map(p)
+    assert list(back) == list(emap) and all(np.array_equal(back[k], emap[k]) for k in emap)   # insertion order kept
+    v = rng.random((5, 4)).astype(np.float32)
+    index.save_shard(str(tmp_path / "sh"), 1, 2, 3, v[3:], ["d", "e"])
+    index.save_shard(str(tmp_path / "sh"), 0, 2, 0, v[:3], ["a", "b", "c"])
+    vecs, paths = index.load_shards(str(tmp_path / "sh"))
+    assert np.array_equal(vecs, v) and paths == list("abcde")
