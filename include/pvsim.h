@@ -166,6 +166,35 @@ int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, i
 int pvs_topk_merge_dev(pvs_ctx* ctx, const int64_t* d_idx_lists, const float* d_val_lists, int n_lists,
                        int64_t nq, int k, int64_t* d_idx, float* d_val);
 
+/* ---------------------------------------------------------------- vocabulary training
+ * Replaces the sklearn fits inside ImageEncoderBase.learn (pyvisim/encoders/_base_encoder.py:311-342: PCA.fit ->
+ * KMeans.fit for VLAD / GaussianMixture(covariance_type="diag").fit for Fisher).  Each entry is ONE pass over the
+ * stacked descriptors on the device; the K x D sized parameter update and the loop control stay with the caller
+ * (pvsim/learn.py).  d_x are plain fp32 rows (n, D), ld = D: make them with pvs_materialise_dev. */
+/* any descriptor kind -> plain fp32 rows (RootSIFT applied for the *_ROOTSIFT kinds). */
+int pvs_materialise_dev(pvs_ctx* ctx, const void* d_desc, int desc_kind, int D, int64_t total_desc, float* d_out);
+/* One Lloyd pass (sklearn/cluster/_kmeans.py:_kmeans_single_lloyd body): labels as KMeans.predict with the centres of
+ * `cb`; h_stats[K*D + K + 2] = [sum over members of (x - c_k) (K*D) | member counts (K) | inertia | number of labels that
+ * differ from d_prev_labels (0 if NULL)].  d_sqdist (optional, f32[n]) receives |x_i - c_label|^2. */
+int pvs_kmeans_step_dev(pvs_ctx* ctx, const pvs_codebook* cb, const float* d_x, int64_t total_desc, int32_t* d_labels,
+                        const int32_t* d_prev_labels, double* h_stats, float* d_sqdist);
+/* One EM pass (sklearn/mixture/_base.py:_e_step + _gaussian_mixture.py:_estimate_gaussian_parameters, fp64):
+ * h_stats[K + 2*K*D + 1] = [sum_i gamma_ik (K) | per k: sum_i gamma_ik x_i (D), sum_i gamma_ik x_i**2 (D) | sum_i log p(x_i)].
+ * K <= 256. */
+int pvs_gmm_em_step_dev(pvs_ctx* ctx, const pvs_gmm* gmm, const float* d_x, int64_t total_desc, double* h_stats);
+/* h_out[K*D]: per label k the sum of x_i (square = 0) or of x_i**2 squared in fp32 (square = 1) over the descriptors with
+ * d_labels[i] == k -- the hard-assignment moments GaussianMixture starts from (sklearn/mixture/_base.py, init_params="kmeans"). */
+int pvs_label_sums_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, const int32_t* d_labels, int K, int square,
+                       double* h_out);
+/* h_out[D + D*D] = [sum_i x_i | sum_i x_i x_i^T] in fp64 (sklearn/decomposition/_pca.py covariance_eigh solver input). */
+int pvs_gram_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, double* h_out);
+/* k-means++ seeding (sklearn/cluster/_kmeans.py:_kmeans_plusplus): for n_cand <= 8 candidate centres (host, f32[n_cand][D])
+ * d_dist[j][i] = |x_i - cand_j|^2 and h_pot[j] = sum_i min(d_mind[i], d_dist[j][i]) (d_mind NULL = +inf). */
+int pvs_seed_distances_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, const float* h_cand, int n_cand,
+                           const float* d_mind, float* d_dist, double* h_pot);
+/* d_mind = min(d_mind, d_dist) (d_dist NULL = keep) and h_block_sums[ceil(n/4096)] = fp64 sums of d_mind per 4096 entries. */
+int pvs_min_update_dev(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total_desc, double* h_block_sums);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py) */
 /* Enable per-kernel-family HIP-event timing on the context's stream. which: 0 assign, 1 aggregate,
  * 2 cosine gemm, 3 top-k, 4 fisher posterior, 5 fisher moments, 6 norms/misc. */

@@ -118,7 +118,7 @@ def vlad_encode(desc_list, centroids, power=1, norm_order=2, eps=1e-9, pca=None)
 
 
 # ----------------------------------------------------------------------------- a6 GMM posterior
-def gmm_predict_proba(x, weights, means, covariances) -> np.ndarray:
+def gmm_predict_proba(x, weights, means, covariances, return_log_prob_norm=False) -> np.ndarray:
     """Call site fisher_vector.py:99.  sklearn/mixture/_base.py:393-411,513-538 and
     sklearn/mixture/_gaussian_mixture.py:413-450,495-512 ('diag'):
       prec_chol = 1/sqrt(cov); precisions = prec_chol**2; log_det = sum log prec_chol
@@ -143,6 +143,8 @@ def gmm_predict_proba(x, weights, means, covariances) -> np.ndarray:
     wlp = lg + np.log(weights)
     m = np.max(wlp, axis=1, keepdims=True)                       # scipy.special.logsumexp
     lse = m[:, 0] + np.log(np.sum(np.exp(wlp - m), axis=1))
+    if return_log_prob_norm:
+        return np.exp(wlp - lse[:, None]), lse
     return np.exp(wlp - lse[:, None])
 
 
@@ -251,3 +253,96 @@ def top_k_map(q_vecs, q_labels, db_vecs, db_labels, k=None) -> float:
         big_r = int(rel.sum())
         aps.append(psum / big_r if big_r > 0 else 0.0)
     return float(np.mean(aps))
+
+
+# ----------------------------------------------------------------------------- f4 learn(): the scikit-learn fits
+# Call site _base_encoder.py:311-342: PCA(n_components).fit / KMeans(n_clusters, **kw).fit /
+# GaussianMixture(n_components, covariance_type="diag", **kw).fit on the stacked descriptors.  The arithmetic is
+# scikit-learn's (1.7.2, not vendored by the reference); restated from its published sources and pinned by the fits
+# the reference's own learn() produced here (tests/golden/learn_k16_d32.npz, tests/golden/make_golden_learn.py).
+def pca_fit(x: np.ndarray, n_components: int):
+    """sklearn/decomposition/_pca.py:_fit_full, solver "covariance_eigh" (what "auto" selects for n >= 10 D, D <= 1000):
+    everything in X's dtype; C = X^T X - n mean mean^T, / (n - 1); eigh; descending; svd_flip(u_based_decision=False)."""
+    x = np.asarray(x)
+    n, d = x.shape
+    mean = x.mean(axis=0)
+    c = x.T @ x
+    c -= n * mean.reshape(-1, 1) * mean.reshape(1, -1)
+    c /= n - 1
+    vals, vecs = np.linalg.eigh(c)
+    vals, vecs = vals[::-1].copy(), vecs[:, ::-1]
+    vals[vals < 0.0] = 0.0
+    vt = vecs.T.copy()
+    piv = np.argmax(np.abs(vt), axis=1)
+    vt *= np.sign(vt[np.arange(d), piv])[:, None]
+    return vt[:n_components].copy(), mean, vals[:n_components].copy()
+
+
+def kmeans_lloyd(x: np.ndarray, init: np.ndarray, max_iter: int = 300, tol: float = 1e-4):
+    """sklearn/cluster/_kmeans.py:KMeans.fit (init given as an array, n_init=1) -> _kmeans_single_lloyd, fp32:
+    X and the start are centred by X.mean(0); tol is scaled by mean(var(X, 0)); each iteration labels with the old
+    centres (a3), moves every centre to its members' mean, relocates empty clusters to the farthest points
+    (_k_means_common.pyx:_relocate_empty_clusters_dense); stops when the labels repeat or sum |shift|^2 <= tol; reruns
+    the labelling unless the labels repeated; inertia = sum |x - c_label|^2.  -> (centres, labels, inertia, n_iter)"""
+    x = np.array(x, dtype=np.float32)
+    mean = x.mean(axis=0)
+    x -= mean
+    c = np.array(init, dtype=np.float32) - mean
+    k = c.shape[0]
+    tol_abs = 0 if tol == 0 else np.mean(np.var(x, axis=0)) * tol
+    labels_old = np.full(x.shape[0], -1, np.int32)
+    strict = False
+    it = 0
+    for it in range(max_iter):
+        labels = kmeans_predict(x, c).astype(np.int32)
+        sums = np.zeros_like(c)
+        np.add.at(sums, labels, x)
+        cnt = np.bincount(labels, minlength=k).astype(np.float32)
+        empty = np.where(cnt == 0)[0]
+        if len(empty):
+            dist = ((x - c[labels]) ** 2).sum(axis=1)
+            far = np.argpartition(dist, -len(empty))[:-len(empty) - 1:-1]
+            for new_id, idx in zip(empty, far):
+                old = labels[idx]
+                sums[old] -= x[idx]
+                sums[new_id] = x[idx]
+                cnt[new_id] = 1
+                cnt[old] -= 1
+        new = sums / cnt[:, None]
+        shift = float(((new - c) ** 2).sum())
+        c = new
+        if np.array_equal(labels, labels_old):
+            strict = True
+            break
+        if shift <= tol_abs:
+            break
+        labels_old = labels
+    if not strict:
+        labels = kmeans_predict(x, c).astype(np.int32)
+    inertia = float(((x - c[labels]).astype(np.float64) ** 2).sum())
+    return c + mean, labels, inertia, it + 1
+
+
+def gmm_em(x, weights, means, covariances, max_iter: int = 100, tol: float = 1e-3, reg_covar: float = 1e-6):
+    """sklearn/mixture/_base.py:BaseMixture.fit_predict main loop with explicit starting tables, 'diag':
+    E-step (a6) -> M-step (_gaussian_mixture.py:_estimate_gaussian_parameters: nk = sum resp + 10 eps;
+    means = resp^T X / nk; cov = resp^T (X*X) / nk - means^2 + reg_covar; weights = nk / n, renormalised) ->
+    lower bound = mean log p(x) under the OLD tables; stop when it changes by less than tol.
+    -> (weights, means, covariances, lower_bound, n_iter, converged)"""
+    x = np.asarray(x)
+    n = x.shape[0]
+    w, mu, cov = (np.asarray(a, dtype=np.float64) for a in (weights, means, covariances))
+    lower, converged, it = -np.inf, False, 0
+    for it in range(1, max_iter + 1):
+        prev = lower
+        resp, lpn = gmm_predict_proba(x, w, mu, cov, return_log_prob_norm=True)
+        nk = resp.sum(axis=0) + 10 * np.finfo(resp.dtype).eps
+        mu = np.dot(resp.T, x) / nk[:, None]
+        cov = np.dot(resp.T, x * x) / nk[:, None] - mu ** 2 + reg_covar
+        w = nk / n
+        w /= w.sum()
+        lower = float(np.mean(lpn))
+        if abs(lower - prev) < tol:
+            converged = True
+            break
+    return w, mu, cov, lower, it, converged

@@ -236,7 +236,9 @@ PVS_EXPORT int pvs_gmm_create(pvs_ctx* ctx, const double* weights, const double*
   //   prec_chol = 1/sqrt(cov); precisions = prec_chol^2; log_det = sum log(prec_chol)
   //   const_k = -0.5*(D*log(2 pi) + sum_d mu^2 prec) + log_det + log(w_k)
   std::vector<double> prec((size_t)K * D), mup((size_t)K * D), cst(K), inv_mu((size_t)K * D), inv_sg((size_t)K * D);
-  const double log2pi = std::log(2.0 * M_PI);
+  // descriptors are fp32: sklearn casts log(2 pi) to X's dtype (_gaussian_mixture.py:512); it cancels in predict_proba
+  // but not in the EM lower bound
+  const double log2pi = (double)(float)std::log(2.0 * M_PI);
   for (int k = 0; k < K; ++k) {
     double s = 0.0, ld = 0.0;
     for (int d = 0; d < D; ++d) {
@@ -713,6 +715,117 @@ PVS_EXPORT int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const f
   PVS_HIP(hipMemcpyAsync(out_val, d_val, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
   PVS_HIP(hipStreamSynchronize(ctx->stream));
   return PVS_OK;
+}
+
+// ================================================================================ vocabulary training
+static int stats_to_host(pvs_ctx* ctx, const double* d_stats, size_t n, double* h_out) {
+  PVS_HIP(hipMemcpyAsync(h_out, d_stats, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_materialise_dev(pvs_ctx* ctx, const void* d_desc, int desc_kind, int D, int64_t total_desc, float* d_out) {
+  PVS_NEED(ctx, "ctx");
+  PVS_TRY(check_kind(desc_kind));
+  if (total_desc < 0 || D <= 0) PVS_FAIL(PVS_ERR_INVALID, "bad sizes");
+  if (total_desc == 0) return PVS_OK;
+  PVS_NEED(d_desc, "descriptors");
+  PVS_NEED(d_out, "out");
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_materialise(ctx, d_desc, desc_kind, total_desc, D, d_out);
+}
+
+PVS_EXPORT int pvs_kmeans_step_dev(pvs_ctx* ctx, const pvs_codebook* cb, const float* d_x, int64_t total_desc, int32_t* d_labels,
+                                   const int32_t* d_prev_labels, double* h_stats, float* d_sqdist) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(cb, "codebook");
+  PVS_NEED(d_x, "descriptors");
+  PVS_NEED(d_labels, "labels");
+  PVS_NEED(h_stats, "stats");
+  if (total_desc <= 0) PVS_FAIL(PVS_ERR_INVALID, "k-means needs at least one descriptor");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const size_t n = (size_t)cb->K * cb->D + cb->K + 2;
+  double* d_stats = nullptr;
+  PVS_TRY(ws_reserve(ctx, 2, n * sizeof(double), reinterpret_cast<void**>(&d_stats)));
+  PVS_TRY(launch_kmeans_step(ctx, cb, d_x, total_desc, d_labels, d_prev_labels, d_stats, d_sqdist));
+  return stats_to_host(ctx, d_stats, n, h_stats);
+}
+
+PVS_EXPORT int pvs_gmm_em_step_dev(pvs_ctx* ctx, const pvs_gmm* gmm, const float* d_x, int64_t total_desc, double* h_stats) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(gmm, "gmm");
+  PVS_NEED(d_x, "descriptors");
+  PVS_NEED(h_stats, "stats");
+  if (total_desc <= 0) PVS_FAIL(PVS_ERR_INVALID, "GMM training needs at least one descriptor");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const size_t n = (size_t)gmm->K + (size_t)2 * gmm->K * gmm->D + 1;
+  double* d_stats = nullptr;
+  PVS_TRY(ws_reserve(ctx, 2, n * sizeof(double), reinterpret_cast<void**>(&d_stats)));
+  PVS_TRY(launch_gmm_em_step(ctx, gmm, d_x, gmm->D, total_desc, d_stats));
+  return stats_to_host(ctx, d_stats, n, h_stats);
+}
+
+PVS_EXPORT int pvs_label_sums_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, const int32_t* d_labels, int K, int square,
+                                  double* h_out) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(d_x, "descriptors");
+  PVS_NEED(d_labels, "labels");
+  PVS_NEED(h_out, "out");
+  if (total_desc <= 0 || D <= 0 || K <= 0) PVS_FAIL(PVS_ERR_INVALID, "bad sizes");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const size_t n = (size_t)K * D;
+  double* d_out = nullptr;
+  PVS_TRY(ws_reserve(ctx, 2, n * sizeof(double), reinterpret_cast<void**>(&d_out)));
+  PVS_TRY(launch_label_sums(ctx, d_x, total_desc, D, d_labels, K, square, d_out));
+  return stats_to_host(ctx, d_out, n, h_out);
+}
+
+PVS_EXPORT int pvs_gram_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, double* h_out) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(d_x, "descriptors");
+  PVS_NEED(h_out, "out");
+  if (total_desc <= 0 || D <= 0) PVS_FAIL(PVS_ERR_INVALID, "the Gram matrix needs at least one row");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const size_t n = (size_t)D + (size_t)D * D;
+  double* d_out = nullptr;
+  PVS_TRY(ws_reserve(ctx, 2, n * sizeof(double), reinterpret_cast<void**>(&d_out)));
+  PVS_TRY(launch_gram(ctx, d_x, total_desc, D, d_out));
+  return stats_to_host(ctx, d_out, n, h_out);
+}
+
+PVS_EXPORT int pvs_seed_distances_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, const float* h_cand, int n_cand,
+                                      const float* d_mind, float* d_dist, double* h_pot) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(d_x, "descriptors");
+  PVS_NEED(h_cand, "candidates");
+  PVS_NEED(d_dist, "dist");
+  PVS_NEED(h_pot, "pot");
+  if (n_cand < 1 || n_cand > 8 || D <= 0) PVS_FAIL(PVS_ERR_INVALID, "1..8 candidates of positive dimension");
+  PVS_HIP(hipSetDevice(ctx->device));
+  char* ws = nullptr;
+  const size_t cand_b = ((size_t)n_cand * D * 4 + 255) / 256 * 256;
+  PVS_TRY(ws_reserve(ctx, 2, cand_b + 8 * sizeof(double), reinterpret_cast<void**>(&ws)));
+  float* d_cand = reinterpret_cast<float*>(ws);
+  double* d_pot = reinterpret_cast<double*>(ws + cand_b);
+  PVS_HIP(hipMemcpyAsync(d_cand, h_cand, (size_t)n_cand * D * 4, hipMemcpyHostToDevice, ctx->stream));
+  PVS_TRY(launch_seed_distances(ctx, d_x, total_desc, D, d_cand, n_cand, d_mind, d_dist, d_pot));
+  double pot8[8];
+  PVS_TRY(stats_to_host(ctx, d_pot, 8, pot8));
+  for (int j = 0; j < n_cand; ++j) h_pot[j] = pot8[j];
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_min_update_dev(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total_desc, double* h_block_sums) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(d_mind, "mind");
+  PVS_NEED(h_block_sums, "block sums");
+  if (total_desc <= 0) PVS_FAIL(PVS_ERR_INVALID, "empty input");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const size_t nblk = (size_t)((total_desc + 4095) / 4096);
+  double* d_bs = nullptr;
+  PVS_TRY(ws_reserve(ctx, 2, nblk * sizeof(double), reinterpret_cast<void**>(&d_bs)));
+  PVS_TRY(launch_min_update(ctx, d_mind, d_dist, total_desc, d_bs));
+  return stats_to_host(ctx, d_bs, nblk, h_block_sums);
 }
 
 // ================================================================================ timers

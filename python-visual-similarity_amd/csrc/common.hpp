@@ -123,7 +123,7 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
                   int32_t* d_labels);
 int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int ld,
                           const int64_t* d_offsets, int64_t n_images, const int32_t* d_labels,
-                          const pvs_norm_params& prm, float* d_out, float* d_inv_norm);
+                          const pvs_norm_params& prm, float* d_out, float* d_inv_norm, bool raw = false);
 int launch_row_inv_norms(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L, float* d_inv);
 int launch_cosine_f32(pvs_ctx* ctx, const float* A, int64_t M, const float* B, int64_t N, int64_t L,
                       const float* inva, const float* invb, float* out, int64_t ldo);
@@ -142,5 +142,16 @@ int launch_gmm_posterior(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int
                          double* d_resp);
 int launch_fisher(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int kind, int ld, const int64_t* d_offsets,
                   int64_t n_images, int64_t total, const pvs_norm_params& prm, void* d_out, int out_f64);
+
+// training (learn.hip / fisher.hip); x are plain fp32 rows (launch_materialise output), ld = D
+int launch_materialise(pvs_ctx* ctx, const void* d_desc, int kind, int64_t total, int D, float* d_out);
+int launch_gmm_em_step(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, int64_t total, double* d_stats);
+int launch_kmeans_step(pvs_ctx* ctx, const pvs_codebook* cb, const float* x, int64_t total, int32_t* d_labels,
+                       const int32_t* d_prev_labels, double* d_stats, float* d_sqdist);
+int launch_label_sums(pvs_ctx* ctx, const float* x, int64_t total, int D, const int32_t* d_labels, int K, int square, double* d_out);
+int launch_gram(pvs_ctx* ctx, const float* x, int64_t total, int D, double* d_out);
+int launch_seed_distances(pvs_ctx* ctx, const float* x, int64_t total, int D, const float* d_cand, int n_cand,
+                          const float* d_mind, float* d_dist, double* d_pot);
+int launch_min_update(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total, double* d_block_sums);
 
 }  // namespace pvs

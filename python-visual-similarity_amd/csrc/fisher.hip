@@ -12,8 +12,8 @@
 //
 // The reference computes this path in fp64 and returns fp64; the covariance floor (1e-6 -> precision 1e6)
 // makes the log-density a sum of large cancelling terms, so the device path keeps fp64 arithmetic
-// (MI355X runs fp64 at half the fp32 rate -- cheaper than losing 3 digits).  Round-1 kernels use vector
-// fp64 FMA with LDS-broadcast operands; v_mfma_f64_16x16x4 is the planned upgrade.
+// (MI355X runs fp64 at half the fp32 rate -- cheaper than losing 3 digits).  K <= 256 runs on v_mfma_f64_16x16x4
+// (posterior as one GEMM over [x | x**2], moments as gamma^T [x | x**2]); larger K uses the vector-FMA kernels.
 #include <algorithm>
 
 #include "common.hpp"
@@ -50,6 +50,20 @@ static int materialise_f32(pvs_ctx* ctx, const void*& d_desc, int& kind, int64_t
   PVS_HIP(hipGetLastError());
   d_desc = buf;
   kind = PVS_DESC_F32;
+  return PVS_OK;
+}
+
+// plain fp32 rows of any descriptor kind (RootSIFT applied) into a caller buffer: the training entry points work on these
+int launch_materialise(pvs_ctx* ctx, const void* d_desc, int kind, int64_t total, int D, float* d_out) {
+  if (total <= 0) return PVS_OK;
+  const dim3 grid((unsigned)((total + 3) / 4));
+  switch (kind) {
+    case PVS_DESC_F32: hipLaunchKernelGGL(materialise_kernel<PVS_DESC_F32>, grid, dim3(256), 0, ctx->stream, d_desc, total, D, d_out); break;
+    case PVS_DESC_F32_ROOTSIFT: hipLaunchKernelGGL(materialise_kernel<PVS_DESC_F32_ROOTSIFT>, grid, dim3(256), 0, ctx->stream, d_desc, total, D, d_out); break;
+    case PVS_DESC_U8_ROOTSIFT: hipLaunchKernelGGL(materialise_kernel<PVS_DESC_U8_ROOTSIFT>, grid, dim3(256), 0, ctx->stream, d_desc, total, D, d_out); break;
+    default: PVS_FAIL(PVS_ERR_INVALID, "unknown descriptor kind %d", kind);
+  }
+  PVS_HIP(hipGetLastError());
   return PVS_OK;
 }
 
@@ -251,6 +265,7 @@ struct PostMArgs {
   const double* tab2;  // [K][2D]: mu*prec | -0.5*prec
   const double* cst;   // [K]
   double* resp;        // [total][K]
+  double* lse;         // [total] log sum_k exp(logp) per descriptor (training: the EM lower bound), or null
 };
 
 // 8 waves: wave = (wm, wn), wm = wave >> 2 owns descriptors [64 wm, +64), wn = wave & 3 owns clusters [64 wn, +64)
@@ -342,6 +357,7 @@ __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostM
           const int k = wn * 64 + 16 * ni + col;
           if (k < a.K) a.resp[(r0 + row) * a.K + k] = exp(acc[mi][ni][r] - lse);
         }
+        if (a.lse != nullptr && wn == 0 && col == 0) a.lse[r0 + row] = lse;
       }
     }
 }
@@ -370,6 +386,8 @@ struct MomMArgs {
   int out_f64;
   double* partial;      // [n_images][dblocks]
   int dblocks;
+  double* raw_s;        // RAW: [n_images][K][2D]  sum_i gamma x | sum_i gamma x**2
+  double* raw_s0;       // RAW: [n_images][K]      sum_i gamma
 };
 
 __device__ __forceinline__ double power_norm64(double v, double p);
@@ -382,6 +400,8 @@ __device__ __forceinline__ void store_out(void* out, int f64, int64_t i, T v) {
 
 constexpr int MM_THREADS = 512, MM_DIMS = 64;
 
+// RAW = leave the sums as they are (one EM M-step's sufficient statistics per descriptor chunk) instead of the Fisher epilogue
+template <bool RAW>
 __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomMArgs a) {
   __shared__ double la[256 * F64_KCP];   // gamma^T chunk: [k][i]
   __shared__ double lb[128 * F64_KCP];   // Z chunk:       [c][i], c = 64 wn + (x: 0..31 | x**2: 32..63)
@@ -428,6 +448,27 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
   }
   if (tid < 256) s0s[tid] = s0;
   __syncthreads();
+
+  if constexpr (RAW) {
+    const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = wm * 64 + 16 * mi + 4 * r + rq;
+        if (k >= K) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int d = d0 + 16 * ni + col;
+          if (d >= D) continue;
+          double* o = a.raw_s + ((int64_t)img * K + k) * 2 * D;
+          o[d] = acc[mi][ni][r];
+          o[D + d] = acc[mi][ni + 2][r];
+        }
+      }
+    if (blockIdx.x == 0 && tid < K) a.raw_s0[(int64_t)img * K + tid] = s0s[tid];
+    return;
+  }
 
   // Epilogue arithmetic: fp64 divisions and square roots cost tens of instructions each, and this epilogue is as long
   // as the MFMA loop if written literally.  The per-(k,d) divisors 1/(sqrt(w) sqrt(cov)) and 1/(sqrt(2) sqrt(w) cov)
@@ -680,11 +721,11 @@ __global__ void build_tab2_kernel(const double* __restrict__ prec, const double*
 }
 
 static int posterior_mfma_on(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, int64_t total, double* d_resp,
-                             double* tab2) {
+                             double* tab2, double* d_lse = nullptr) {
   const int64_t kd = (int64_t)g->K * g->D;
   hipLaunchKernelGGL(build_tab2_kernel, dim3((unsigned)((kd + 255) / 256)), dim3(256), 0, ctx->stream, g->d_prec, g->d_mup,
                      g->K, g->D, tab2);
-  PostMArgs a{x, total, g->D, ld, g->K, tab2, g->d_const, d_resp};
+  PostMArgs a{x, total, g->D, ld, g->K, tab2, g->d_const, d_resp, d_lse};
   ScopedTimer tm(ctx, T_FPOST);
   hipLaunchKernelGGL(gmm_posterior_mfma_kernel, dim3((unsigned)((total + PM_ROWS - 1) / PM_ROWS)), dim3(PM_THREADS), 0, ctx->stream, a);
   PVS_HIP(hipGetLastError());
@@ -729,8 +770,8 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
   ScopedTimer tm(ctx, T_FMOM);
   if (mfma) {
     MomMArgs m{x, D, ld, K, d_offsets + img0, resp_abs, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, prm.power_norm_weight, norm_mode, ord,
-               out_b, out_f64, partial, dblocks};
-    hipLaunchKernelGGL(fisher_moments_mfma_kernel, dim3((unsigned)dblocks, (unsigned)n_img), dim3(MM_THREADS), 0, ctx->stream, m);
+               out_b, out_f64, partial, dblocks, nullptr, nullptr};
+    hipLaunchKernelGGL(fisher_moments_mfma_kernel<false>, dim3((unsigned)dblocks, (unsigned)n_img), dim3(MM_THREADS), 0, ctx->stream, m);
   } else {
     MomArgs a{};
     a.X = x; a.D = D; a.ld = ld; a.K = K; a.offsets = d_offsets + img0; a.resp = resp_abs;
@@ -746,6 +787,83 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
   hipLaunchKernelGGL(fisher_scale_kernel, dim3(sx, (unsigned)n_img), dim3(256), 0, ctx->stream, out_b, out_f64, L, partial, bpi,
                      norm_mode, ord, prm.epsilon);
   PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+// ------------------------------------------------------------------------------------ training: one EM pass
+__global__ void em_chunk_offsets_kernel(int64_t* off, int64_t t0, int64_t tn, int chunk, int64_t nchunks) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= nchunks) off[i] = t0 + (i * chunk < tn ? i * chunk : tn);
+}
+
+// acc[j] (+)= part[0][j] + part[1][j] + ... in chunk order (fixed order: run-to-run identical)
+__global__ __launch_bounds__(256) void em_reduce_chunks_kernel(const double* __restrict__ part, int64_t nchunks, int64_t len,
+                                                               double* __restrict__ acc, int first) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= len) return;
+  double t = first ? 0.0 : acc[j];
+  for (int64_t c = 0; c < nchunks; ++c) t += part[c * len + j];
+  acc[j] = t;
+}
+
+// single block: acc (+)= sum of v[0..n) -- thread t takes t, t+256, ...; fixed tree afterwards
+__global__ __launch_bounds__(256) void em_sum_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ acc, int first) {
+  __shared__ double sh[256];
+  double t = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) t += v[i];
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc[0] = (first ? 0.0 : acc[0]) + sh[0];
+}
+
+// E-step + sufficient statistics of one EM iteration (sklearn/mixture/_base.py:_e_step, _gaussian_mixture.py:
+// _estimate_gaussian_parameters): d_stats = [s0 (K) | per k: sum gamma x (D), sum gamma x**2 (D)] and
+// d_stats[K + 2KD] = sum_i log p(x_i).  The descriptors go through in batches of fixed-size chunks; every chunk's sums
+// are formed by the Fisher moments kernel (RAW) and the chunks are added in order, in fp64.
+int launch_gmm_em_step(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, int64_t total, double* d_stats) {
+  const int K = g->K, D = g->D;
+  if (K > PM_COLS) PVS_FAIL(PVS_ERR_UNSUPPORTED, "GMM training on the device supports at most %d components (got %d)", PM_COLS, K);
+  if (total <= 0) PVS_FAIL(PVS_ERR_INVALID, "GMM training needs at least one descriptor");
+  constexpr int CHUNK = 2048;
+  const int64_t len = (int64_t)K * 2 * D;
+  const size_t tab_b = ((size_t)2 * K * D * 8 + 255) / 256 * 256;
+  const int64_t rows_per_batch = std::max<int64_t>(CHUNK, (((int64_t)2 << 30) / ((int64_t)K * 8)) / CHUNK * CHUNK);
+  const int dblocks = (D + MM_DIMS - 1) / MM_DIMS;
+  int first = 1;
+  for (int64_t t0 = 0; t0 < total; t0 += rows_per_batch) {
+    const int64_t tn = std::min(rows_per_batch, total - t0);
+    const int64_t nch = (tn + CHUNK - 1) / CHUNK;
+    const size_t resp_b = ((size_t)tn * K * 8 + 255) / 256 * 256;
+    const size_t lse_b = ((size_t)tn * 8 + 255) / 256 * 256;
+    const size_t off_b = ((size_t)(nch + 1) * 8 + 255) / 256 * 256;
+    const size_t raw_b = ((size_t)nch * len * 8 + 255) / 256 * 256;
+    const size_t s0_b = ((size_t)nch * K * 8 + 255) / 256 * 256;
+    char* ws = nullptr;
+    PVS_TRY(ws_reserve(ctx, 1, tab_b + resp_b + lse_b + off_b + raw_b + s0_b, reinterpret_cast<void**>(&ws)));
+    double* tab = reinterpret_cast<double*>(ws);
+    double* resp = reinterpret_cast<double*>(ws + tab_b);
+    double* lse = reinterpret_cast<double*>(ws + tab_b + resp_b);
+    int64_t* off = reinterpret_cast<int64_t*>(ws + tab_b + resp_b + lse_b);
+    double* raw = reinterpret_cast<double*>(ws + tab_b + resp_b + lse_b + off_b);
+    double* raw0 = reinterpret_cast<double*>(ws + tab_b + resp_b + lse_b + off_b + raw_b);
+    PVS_TRY(posterior_mfma_on(ctx, g, x + t0 * ld, ld, tn, resp, tab, lse));
+    hipLaunchKernelGGL(em_chunk_offsets_kernel, dim3((unsigned)((nch + 256) / 256)), dim3(256), 0, ctx->stream, off, t0, tn, CHUNK, nch);
+    {
+      ScopedTimer tm(ctx, T_FMOM);
+      MomMArgs m{x, D, ld, K, off, resp - t0 * K, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, 1.0, 2, 2.0,
+                 nullptr, 1, nullptr, dblocks, raw, raw0};
+      hipLaunchKernelGGL(fisher_moments_mfma_kernel<true>, dim3((unsigned)dblocks, (unsigned)nch), dim3(MM_THREADS), 0, ctx->stream, m);
+    }
+    hipLaunchKernelGGL(em_reduce_chunks_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, raw0, nch, (int64_t)K, d_stats, first);
+    hipLaunchKernelGGL(em_reduce_chunks_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, raw, nch, len, d_stats + K, first);
+    hipLaunchKernelGGL(em_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, lse, tn, d_stats + K + len, first);
+    PVS_HIP(hipGetLastError());
+    first = 0;
+  }
   return PVS_OK;
 }
 

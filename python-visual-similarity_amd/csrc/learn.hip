@@ -1,0 +1,406 @@
+// Vocabulary training on gfx950: the device side of ImageEncoderBase.learn (reference:
+// pyvisim/encoders/_base_encoder.py:311-342, which fits sklearn KMeans / GaussianMixture / PCA on the stacked
+// descriptors).  The heavy passes reuse the encode kernels -- the centroid assignment (f32 MFMA) and the raw residual
+// sums of the VLAD aggregate for a Lloyd iteration, the fp64 MFMA posterior + moments for an EM iteration (fisher.hip)
+// -- and this file adds the reductions around them.  The host keeps only the K x D sized updates and the loop control
+// (python-visual-similarity_amd/pvsim/learn.py).
+//
+//   Lloyd iteration  sklearn/cluster/_kmeans.py:_kmeans_single_lloyd -> _k_means_lloyd.pyx:lloyd_iter_chunked_dense:
+//                    labels = argmin_k (|c_k|^2 - 2 x.c_k); new centre = mean of the members.
+//   k-means++        sklearn/cluster/_kmeans.py:_kmeans_plusplus (greedy variant: 2 + log K candidates per step).
+//   PCA.fit          sklearn/decomposition/_pca.py:_fit_full, svd_solver "covariance_eigh": eigenvectors of the covariance.
+//
+// Every sum below is formed in a fixed order (chunk partial sums added in chunk order, fixed reduction trees), so a fit
+// is run-to-run identical.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace pvs {
+
+constexpr int LEARN_CHUNK = 4096;  // descriptors per pseudo-image of the aggregate pass (its LDS sort width)
+
+__global__ void learn_chunk_offsets_kernel(int64_t* off, int64_t t0, int64_t tn, int chunk, int64_t nchunks) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= nchunks) off[i] = t0 + (i * chunk < tn ? i * chunk : tn);
+}
+
+// acc[j] (+)= part[0][j] + part[1][j] + ...  in chunk order, fp64
+__global__ __launch_bounds__(256) void learn_reduce_f32_kernel(const float* __restrict__ part, int64_t nchunks, int64_t len,
+                                                               double* __restrict__ acc, int first) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= len) return;
+  double t = first ? 0.0 : acc[j];
+  for (int64_t c = 0; c < nchunks; ++c) t += (double)part[c * len + j];
+  acc[j] = t;
+}
+
+__global__ __launch_bounds__(256) void learn_reduce_f64_kernel(const double* __restrict__ part, int64_t nchunks, int64_t len,
+                                                               double* __restrict__ acc, int first) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= len) return;
+  double t = first ? 0.0 : acc[j];
+  for (int64_t c = 0; c < nchunks; ++c) t += part[c * len + j];
+  acc[j] = t;
+}
+
+// single block: acc[0] (+)= sum v[0..n)
+__global__ __launch_bounds__(256) void learn_sum_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ acc, int first) {
+  __shared__ double sh[256];
+  double t = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) t += v[i];
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc[0] = (first ? 0.0 : acc[0]) + sh[0];
+}
+
+// member counts (integer atomics: order independent) and the number of labels that changed since the last pass
+__global__ __launch_bounds__(256) void learn_label_stats_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ prev,
+                                                                int64_t total, int K, unsigned long long* __restrict__ counts,
+                                                                unsigned long long* __restrict__ changed) {
+  extern __shared__ unsigned int lh[];  // [K]
+  for (int k = threadIdx.x; k < K; k += 256) lh[k] = 0u;
+  __syncthreads();
+  unsigned int diff = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int l = labels[i];
+    atomicAdd(&lh[l], 1u);
+    if (prev != nullptr && prev[i] != l) ++diff;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256)
+    if (lh[k]) atomicAdd(&counts[k], (unsigned long long)lh[k]);
+  if (prev == nullptr) diff = 0;
+  for (int m = 32; m >= 1; m >>= 1) diff += __shfl_xor(diff, m, 64);
+  if ((threadIdx.x & 63) == 0 && diff) atomicAdd(changed, (unsigned long long)diff);
+}
+
+__global__ void learn_counts_to_f64_kernel(const unsigned long long* __restrict__ c, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)c[i];
+}
+
+// squared distance of every descriptor to its own centre (fp32 per lane, xor tree over the wave) and, per block of
+// 64 descriptors, their fp64 sum: the inertia (sklearn/cluster/_k_means_common.pyx:_inertia_dense) and the input of
+// the empty-cluster relocation (_relocate_empty_clusters_dense).
+__global__ __launch_bounds__(256) void learn_sqdist_kernel(const float* __restrict__ X, int64_t total, int D,
+                                                           const int32_t* __restrict__ labels, const float* __restrict__ cent,
+                                                           float* __restrict__ sq, double* __restrict__ block_sum) {
+  __shared__ float rows[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int j = 0; j < 16; ++j) {
+    const int64_t row = r0 + wave * 16 + j;
+    float s = 0.f;
+    if (row < total) {
+      const float* c = cent + (int64_t)labels[row] * D;
+      for (int d = lane; d < D; d += 64) {
+        const float t = X[row * D + d] - c[d];
+        s = fmaf(t, t, s);
+      }
+    }
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) {
+      rows[wave * 16 + j] = s;
+      if (row < total && sq != nullptr) sq[row] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int j = 0; j < 64; ++j) t += (double)rows[j];
+    block_sum[blockIdx.x] = t;
+  }
+}
+
+// One Lloyd pass over the descriptors with the centres of `cb`:
+//   d_labels[i]            nearest centre (first minimum), as KMeans.predict
+//   d_stats[0 .. K*D)      sum over the members of (x - c_k)   (so the new centre is c_k + sum / count)
+//   d_stats[K*D .. +K)     member counts
+//   d_stats[K*D+K]         inertia  sum_i |x_i - c_label|^2
+//   d_stats[K*D+K+1]       number of labels that differ from d_prev_labels (0 when that is null)
+int launch_kmeans_step(pvs_ctx* ctx, const pvs_codebook* cb, const float* x, int64_t total, int32_t* d_labels,
+                       const int32_t* d_prev_labels, double* d_stats, float* d_sqdist) {
+  const int K = cb->K, D = cb->D;
+  if (total <= 0) PVS_FAIL(PVS_ERR_INVALID, "k-means needs at least one descriptor");
+  if (K > 2048) PVS_FAIL(PVS_ERR_UNSUPPORTED, "K = %d exceeds the device k-means limit (2048)", K);
+  const int64_t len = (int64_t)K * D;
+  const int64_t rows_per_batch = (int64_t)LEARN_CHUNK * std::max<int64_t>(1, ((int64_t)1 << 30) / (len * 4));
+  pvs_norm_params prm{1.0, 2.0, 0.0};
+  int first = 1;
+  for (int64_t t0 = 0; t0 < total; t0 += rows_per_batch) {
+    const int64_t tn = std::min(rows_per_batch, total - t0);
+    const int64_t nch = (tn + LEARN_CHUNK - 1) / LEARN_CHUNK;
+    const size_t off_b = ((size_t)(nch + 1) * 8 + 255) / 256 * 256;
+    char* ws = nullptr;
+    PVS_TRY(ws_reserve(ctx, 1, off_b + (size_t)nch * len * 4, reinterpret_cast<void**>(&ws)));
+    int64_t* off = reinterpret_cast<int64_t*>(ws);
+    float* part = reinterpret_cast<float*>(ws + off_b);
+    PVS_TRY(launch_assign(ctx, cb, x + t0 * D, PVS_DESC_F32, tn, D, d_labels + t0));
+    hipLaunchKernelGGL(learn_chunk_offsets_kernel, dim3((unsigned)((nch + 256) / 256)), dim3(256), 0, ctx->stream, off, t0, tn,
+                       LEARN_CHUNK, nch);
+    PVS_TRY(launch_vlad_aggregate(ctx, cb, x, PVS_DESC_F32, D, off, nch, d_labels, prm, part, nullptr, /*raw=*/true));
+    hipLaunchKernelGGL(learn_reduce_f32_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, part, nch, len,
+                       d_stats, first);
+    PVS_HIP(hipGetLastError());
+    first = 0;
+  }
+  // counts, changed labels, inertia
+  const int64_t nblk = (total + 63) / 64;
+  const size_t cnt_b = ((size_t)(K + 1) * 8 + 255) / 256 * 256;
+  char* ws = nullptr;
+  PVS_TRY(ws_reserve(ctx, 1, cnt_b + (size_t)nblk * 8, reinterpret_cast<void**>(&ws)));
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(ws);
+  double* bs = reinterpret_cast<double*>(ws + cnt_b);
+  PVS_HIP(hipMemsetAsync(cnt, 0, (size_t)(K + 1) * 8, ctx->stream));
+  const unsigned hb = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(learn_label_stats_kernel, dim3(hb), dim3(256), (size_t)K * 4, ctx->stream, d_labels, d_prev_labels, total, K,
+                     cnt, cnt + K);
+  hipLaunchKernelGGL(learn_counts_to_f64_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, cnt, K, d_stats + len);
+  hipLaunchKernelGGL(learn_counts_to_f64_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt + K, 1, d_stats + len + K + 1);
+  hipLaunchKernelGGL(learn_sqdist_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, x, total, D, d_labels, cb->d_cent,
+                     d_sqdist, bs);
+  hipLaunchKernelGGL(learn_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, bs, nblk, d_stats + len + K, 1);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+// ------------------------------------------------------------------------------------ per-label sums
+__global__ void learn_square_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[i] * x[i];
+}
+
+// d_out[k][d] = sum over the descriptors labelled k of x_id (square = 0) or x_id**2 squared in fp32 (square = 1): the
+// hard-assignment moments a GMM is initialised from (sklearn/mixture/_base.py:_initialize_parameters, init_params="kmeans").
+// Same machinery as a Lloyd pass: raw aggregate sums against an all-zero centre table, chunks added in order in fp64.
+int launch_label_sums(pvs_ctx* ctx, const float* x, int64_t total, int D, const int32_t* d_labels, int K, int square, double* d_out) {
+  if (total <= 0) PVS_FAIL(PVS_ERR_INVALID, "empty input");
+  if (K > 2048) PVS_FAIL(PVS_ERR_UNSUPPORTED, "K = %d exceeds the device limit (2048)", K);
+  const int64_t len = (int64_t)K * D;
+  const int64_t rows_per_batch = (int64_t)LEARN_CHUNK * std::max<int64_t>(1, ((int64_t)1 << 30) / (len * 4));
+  float* zero = nullptr;
+  PVS_TRY(ws_reserve(ctx, 3, (size_t)len * 4, reinterpret_cast<void**>(&zero)));
+  PVS_HIP(hipMemsetAsync(zero, 0, (size_t)len * 4, ctx->stream));
+  pvs_codebook cb;
+  cb.K = K; cb.D = D; cb.d_cent = zero;
+  pvs_norm_params prm{1.0, 2.0, 0.0};
+  int first = 1;
+  for (int64_t t0 = 0; t0 < total; t0 += rows_per_batch) {
+    const int64_t tn = std::min(rows_per_batch, total - t0);
+    const int64_t nch = (tn + LEARN_CHUNK - 1) / LEARN_CHUNK;
+    const size_t off_b = ((size_t)(nch + 1) * 8 + 255) / 256 * 256;
+    char* ws = nullptr;
+    PVS_TRY(ws_reserve(ctx, 1, off_b + (size_t)nch * len * 4, reinterpret_cast<void**>(&ws)));
+    int64_t* off = reinterpret_cast<int64_t*>(ws);
+    float* part = reinterpret_cast<float*>(ws + off_b);
+    const float* xb = x + t0 * D;   // the batch's rows; offsets and labels below are relative to it
+    if (square) {
+      float* sq = nullptr;
+      PVS_TRY(ws_reserve(ctx, 4, (size_t)tn * D * 4, reinterpret_cast<void**>(&sq)));
+      hipLaunchKernelGGL(learn_square_kernel, dim3(4096), dim3(256), 0, ctx->stream, xb, tn * D, sq);
+      xb = sq;
+    }
+    hipLaunchKernelGGL(learn_chunk_offsets_kernel, dim3((unsigned)((nch + 256) / 256)), dim3(256), 0, ctx->stream, off, (int64_t)0, tn,
+                       LEARN_CHUNK, nch);
+    PVS_TRY(launch_vlad_aggregate(ctx, &cb, xb, PVS_DESC_F32, D, off, nch, d_labels + t0, prm, part, nullptr, /*raw=*/true));
+    hipLaunchKernelGGL(learn_reduce_f32_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, part, nch, len, d_out, first);
+    PVS_HIP(hipGetLastError());
+    first = 0;
+  }
+  return PVS_OK;
+}
+
+// ------------------------------------------------------------------------------------ Gram matrix (PCA.fit)
+// d_out = [sum_i x_i (D) | sum_i x_i x_i^T (D*D)]  in fp64.  Block = 64x64 tile of the Gram matrix for one chunk of rows
+// (upper triangle of tiles only; the host mirrors), 256 threads x (4x4); chunk partials are added in chunk order.
+constexpr int GRAM_ROWS = 8192;
+
+__global__ __launch_bounds__(256) void learn_gram_kernel(const float* __restrict__ X, int64_t total, int D, int ntile,
+                                                         double* __restrict__ part /*[chunk][ntile*ntile][64*64]*/,
+                                                         double* __restrict__ colsum /*[chunk][D]*/) {
+  __shared__ double la[32][65], lb[32][65];
+  const int ti = blockIdx.x / ntile, tj = blockIdx.x % ntile;
+  if (tj < ti) return;
+  const int64_t chunk = blockIdx.y;
+  const int64_t r0 = chunk * GRAM_ROWS, r1 = r0 + GRAM_ROWS < total ? r0 + GRAM_ROWS : total;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double acc[4][4] = {};
+  double cs = 0.0;  // threads 0..63 of diagonal tiles: column sums of tile ti
+  for (int64_t r = r0; r < r1; r += 32) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += 256) {
+      const int rr = idx >> 6, c = idx & 63;
+      const bool in = r + rr < r1;
+      const int da = ti * 64 + c, db = tj * 64 + c;
+      la[rr][c] = (in && da < D) ? (double)X[(r + rr) * D + da] : 0.0;
+      lb[rr][c] = (in && db < D) ? (double)X[(r + rr) * D + db] : 0.0;
+    }
+    __syncthreads();
+    if (ti == tj && threadIdx.x < 64) {
+      for (int rr = 0; rr < 32; ++rr) cs += la[rr][threadIdx.x];
+    }
+    for (int rr = 0; rr < 32; ++rr) {
+      double a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = la[rr][ty * 4 + q];
+        b[q] = lb[rr][tx * 4 + q];
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = fma(a[p], b[q], acc[p][q]);
+    }
+  }
+  double* o = part + ((int64_t)chunk * ntile * ntile + blockIdx.x) * 4096;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[(ty * 4 + p) * 64 + tx * 4 + q] = acc[p][q];
+  if (ti == tj && threadIdx.x < 64 && ti * 64 + (int)threadIdx.x < D) colsum[chunk * D + ti * 64 + threadIdx.x] = cs;
+}
+
+__global__ void learn_gram_scatter_kernel(const double* __restrict__ tiles /*[ntile*ntile][4096]*/, int D, int ntile,
+                                          double* __restrict__ gram) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)D * D) return;
+  const int i = (int)(idx / D), j = (int)(idx % D);
+  const int a = i <= j ? i : j, b = i <= j ? j : i;   // upper-triangle tile holds (a, b)
+  gram[idx] = tiles[((int64_t)(a / 64) * ntile + b / 64) * 4096 + (a % 64) * 64 + (b % 64)];
+}
+
+int launch_gram(pvs_ctx* ctx, const float* x, int64_t total, int D, double* d_out) {
+  if (total <= 0 || D <= 0) PVS_FAIL(PVS_ERR_INVALID, "the Gram matrix needs at least one row");
+  const int ntile = (D + 63) / 64;
+  const int64_t tl = (int64_t)ntile * ntile * 4096;
+  const int64_t nchunk_all = (total + GRAM_ROWS - 1) / GRAM_ROWS;
+  const int64_t per_batch = std::max<int64_t>(1, ((int64_t)1 << 30) / (tl * 8));
+  double* acc = nullptr;
+  PVS_TRY(ws_reserve(ctx, 4, (size_t)tl * 8, reinterpret_cast<void**>(&acc)));
+  int first = 1;
+  for (int64_t c0 = 0; c0 < nchunk_all; c0 += per_batch) {
+    const int64_t nc = std::min(per_batch, nchunk_all - c0);
+    char* ws = nullptr;
+    PVS_TRY(ws_reserve(ctx, 1, (size_t)nc * (tl + D) * 8, reinterpret_cast<void**>(&ws)));
+    double* part = reinterpret_cast<double*>(ws);
+    double* cs = part + nc * tl;
+    const int64_t r0 = c0 * GRAM_ROWS;
+    const int64_t rows = std::min<int64_t>(total - r0, nc * GRAM_ROWS);
+    hipLaunchKernelGGL(learn_gram_kernel, dim3((unsigned)(ntile * ntile), (unsigned)nc), dim3(256), 0, ctx->stream, x + r0 * D, rows, D,
+                       ntile, part, cs);
+    hipLaunchKernelGGL(learn_reduce_f64_kernel, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, ctx->stream, part, nc, tl, acc, first);
+    hipLaunchKernelGGL(learn_reduce_f64_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, cs, nc, (int64_t)D, d_out,
+                       first);
+    PVS_HIP(hipGetLastError());
+    first = 0;
+  }
+  hipLaunchKernelGGL(learn_gram_scatter_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, ctx->stream, acc, D, ntile,
+                     d_out + D);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+// ------------------------------------------------------------------------------------ k-means++ seeding
+// For up to 8 candidate centres: d_dist[j][i] = |x_i - cand_j|^2 (fp32) and d_pot[j] = sum_i min(d_mind[i], d_dist[j][i])
+// -- the potential the seeding would have if candidate j were taken (sklearn _kmeans_plusplus: "best candidate").
+// d_mind null = no centre chosen yet (potential = plain sum of distances).
+constexpr int SEED_MAX = 8;
+
+__global__ __launch_bounds__(256) void learn_seed_kernel(const float* __restrict__ X, int64_t total, int D, const float* __restrict__ cand,
+                                                         int nc, const float* __restrict__ mind, float* __restrict__ dist,
+                                                         double* __restrict__ block_pot /*[nblk][SEED_MAX]*/) {
+  extern __shared__ float sc[];  // [nc][D] candidates, then [64][SEED_MAX] row results
+  float* res = sc + nc * D;
+  for (int i = threadIdx.x; i < nc * D; i += 256) sc[i] = cand[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int j = 0; j < 16; ++j) {
+    const int64_t row = r0 + wave * 16 + j;
+    float s[SEED_MAX];
+#pragma unroll
+    for (int c = 0; c < SEED_MAX; ++c) s[c] = 0.f;
+    if (row < total) {
+      for (int d = lane; d < D; d += 64) {
+        const float xv = X[row * D + d];
+#pragma unroll
+        for (int c = 0; c < SEED_MAX; ++c)
+          if (c < nc) {
+            const float t = xv - sc[c * D + d];
+            s[c] = fmaf(t, t, s[c]);
+          }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < SEED_MAX; ++c)
+      for (int m = 32; m >= 1; m >>= 1) s[c] += __shfl_xor(s[c], m, 64);
+    if (lane == 0) {
+      const float md = (row < total && mind != nullptr) ? mind[row] : INFINITY;
+#pragma unroll
+      for (int c = 0; c < SEED_MAX; ++c) {
+        if (c < nc && row < total) dist[(int64_t)c * total + row] = s[c];
+        res[(wave * 16 + j) * SEED_MAX + c] = (c < nc && row < total) ? fminf(md, s[c]) : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < SEED_MAX) {
+    double t = 0.0;
+    for (int j = 0; j < 64; ++j) t += (double)res[j * SEED_MAX + threadIdx.x];
+    block_pot[(int64_t)blockIdx.x * SEED_MAX + threadIdx.x] = t;
+  }
+}
+
+int launch_seed_distances(pvs_ctx* ctx, const float* x, int64_t total, int D, const float* d_cand, int n_cand,
+                          const float* d_mind, float* d_dist, double* d_pot) {
+  if (n_cand < 1 || n_cand > SEED_MAX) PVS_FAIL(PVS_ERR_INVALID, "1..%d seeding candidates per call (got %d)", SEED_MAX, n_cand);
+  if (total <= 0) PVS_FAIL(PVS_ERR_INVALID, "seeding needs at least one descriptor");
+  const size_t lds = ((size_t)n_cand * D + 64 * SEED_MAX) * 4;
+  if (lds > 64 * 1024) PVS_FAIL(PVS_ERR_UNSUPPORTED, "descriptor dimension %d too large for the seeding kernel", D);
+  const int64_t nblk = (total + 63) / 64;
+  double* bp = nullptr;
+  PVS_TRY(ws_reserve(ctx, 1, (size_t)nblk * SEED_MAX * 8, reinterpret_cast<void**>(&bp)));
+  hipLaunchKernelGGL(learn_seed_kernel, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, x, total, D, d_cand, n_cand, d_mind, d_dist, bp);
+  // block_pot is [nblk][SEED_MAX]: "chunks" = blocks, len = SEED_MAX
+  hipLaunchKernelGGL(learn_reduce_f64_kernel, dim3(1), dim3(256), 0, ctx->stream, bp, nblk, (int64_t)SEED_MAX, d_pot, 1);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+// d_mind = min(d_mind, d_dist) and the fp64 sums of d_mind over blocks of LEARN_CHUNK entries (the host samples the next
+// candidates from these: block by cumulative sum, then the position inside the block)
+__global__ __launch_bounds__(256) void learn_min_update_kernel(float* __restrict__ mind, const float* __restrict__ dist, int64_t total,
+                                                               double* __restrict__ block_sums) {
+  __shared__ double sh[256];
+  const int64_t b0 = (int64_t)blockIdx.x * LEARN_CHUNK;
+  double t = 0.0;
+  for (int i = threadIdx.x; i < LEARN_CHUNK; i += 256) {
+    const int64_t r = b0 + i;
+    if (r < total) {
+      const float v = dist != nullptr ? fminf(mind[r], dist[r]) : mind[r];
+      mind[r] = v;
+      t += (double)v;
+    }
+  }
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
+}
+
+int launch_min_update(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total, double* d_block_sums) {
+  if (total <= 0) return PVS_OK;
+  const int64_t nblk = (total + LEARN_CHUNK - 1) / LEARN_CHUNK;
+  hipLaunchKernelGGL(learn_min_update_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_mind, d_dist, total, d_block_sums);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+}  // namespace pvs

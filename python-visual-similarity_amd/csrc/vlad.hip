@@ -233,7 +233,7 @@ struct AggArgs {
   const float* cent;       // [K][D]
   int K;
   float power, eps;
-  int norm_mode;           // 0: general p, 1: L1, 2: L2, 3: +inf
+  int norm_mode;           // 0: general p, 1: L1, 2: L2, 3: +inf, 4: none (raw residual sums, training)
   float norm_p;
   float* out;              // [n_images][K*D]
   float* inv_norm;         // [n_images] or null
@@ -412,6 +412,18 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
         continue;
       }
 
+      if (a.norm_mode == 4) {  // training pass: the raw residual sums leave as they are
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          const int d0 = (r * GROUP + gl) * VW;
+#pragma unroll
+          for (int q = 0; q < VW; ++q)
+            if (d0 + q < D) out_img[(int64_t)k * D + d0 + q] = acc[r][q];
+        }
+        if (gl == 0) rowsq[k] = 0.f;
+        continue;
+      }
+
       // ---- K3: power norm, per-cluster norm + eps, divide
       float part = 0.f;
 #pragma unroll
@@ -489,7 +501,7 @@ static int launch_agg_kind(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, siz
 
 int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int ld,
                           const int64_t* d_offsets, int64_t n_images, const int32_t* d_labels,
-                          const pvs_norm_params& prm, float* d_out, float* d_inv_norm) {
+                          const pvs_norm_params& prm, float* d_out, float* d_inv_norm, bool raw) {
   if (n_images <= 0) return PVS_OK;
   if (cb->K > 2048) PVS_FAIL(PVS_ERR_UNSUPPORTED, "K = %d exceeds the VLAD aggregate kernel limit (2048)", cb->K);
   if (n_images > 0x7fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "too many images in one call");
@@ -498,7 +510,7 @@ int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_de
   a.K = cb->K; a.power = (float)prm.power_norm_weight; a.eps = (float)prm.epsilon;
   const double ord = prm.norm_order;
   if (std::isnan(ord) || ord <= 0.0) PVS_FAIL(PVS_ERR_UNSUPPORTED, "norm_order must be > 0 or +inf (got %g)", ord);
-  a.norm_mode = std::isinf(ord) ? 3 : (ord == 2.0 ? 2 : (ord == 1.0 ? 1 : 0));
+  a.norm_mode = raw ? 4 : (std::isinf(ord) ? 3 : (ord == 2.0 ? 2 : (ord == 1.0 ? 1 : 0)));
   a.norm_p = (float)ord;
   a.out = d_out; a.inv_norm = d_inv_norm;
   const int esz = kind == PVS_DESC_U8_ROOTSIFT ? 1 : 4;

@@ -70,6 +70,13 @@ SIGNATURES = {
     "pvs_cosine_topk_f16_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _i64, _int, _vp, _vp],
     "pvs_cosine_topk": [_vp, _vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
     "pvs_topk_merge_dev": [_vp, _vp, _vp, _int, _i64, _int, _vp, _vp],
+    "pvs_materialise_dev": [_vp, _vp, _int, _int, _i64, _vp],
+    "pvs_kmeans_step_dev": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "pvs_gmm_em_step_dev": [_vp, _vp, _vp, _i64, _vp],
+    "pvs_label_sums_dev": [_vp, _vp, _int, _i64, _vp, _int, _int, _vp],
+    "pvs_gram_dev": [_vp, _vp, _int, _i64, _vp],
+    "pvs_seed_distances_dev": [_vp, _vp, _int, _i64, _vp, _int, _vp, _vp, _vp],
+    "pvs_min_update_dev": [_vp, _vp, _vp, _i64, _vp],
     "pvs_timers_enable": [_vp, _int],
     "pvs_timers_reset": [_vp],
     "pvs_timers_read": [_vp, _int, C.POINTER(C.c_double), C.POINTER(C.c_int64)],

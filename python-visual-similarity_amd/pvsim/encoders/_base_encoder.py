@@ -315,29 +315,54 @@ class ImageEncoderBase(SimilarityMetric):
     # ---- reference API
     def learn(self, images: Iterable[np.ndarray], /, *, n_clusters: int, dim_reduction_factor: int = None,
               **kwargs) -> None:
-        """Learns the visual vocabulary (reference: _base_encoder.py:311-342).  Training is not on the
-        encode/retrieve hot path; like the reference it is delegated to scikit-learn on the host."""
-        from sklearn.cluster import KMeans
-        from sklearn.decomposition import PCA
-        from sklearn.mixture import GaussianMixture
+        """Learns the visual vocabulary (reference: _base_encoder.py:311-342: PCA.fit -> KMeans.fit for VLAD /
+        GaussianMixture(covariance_type="diag").fit for Fisher, on the stacked descriptors of `images`).
+
+        The fits run on the device (pvsim/learn.py); `kwargs` are the scikit-learn estimator's keyword arguments
+        (KMeans: init, n_init, max_iter, tol, random_state, verbose; GaussianMixture: tol, reg_covar, max_iter, n_init,
+        init_params, weights_init, means_init, precisions_init, random_state, verbose).  Anything else raises
+        TypeError, as an unknown keyword does in scikit-learn."""
         features = np.vstack([self.feature_extractor(image) for image in images])
+        self.learn_from_descriptors(features, n_clusters=n_clusters, dim_reduction_factor=dim_reduction_factor, **kwargs)
+
+    def learn_from_descriptors(self, features, /, *, n_clusters: int, dim_reduction_factor: int = None,
+                               rootsift: bool = False, **kwargs) -> None:
+        """learn() from an already stacked (n, D) descriptor matrix (rootsift=True: raw SIFT rows, uint8 or float32,
+        transformed on the device as in encode_descriptors)."""
+        from .. import learn as _learn
+        features = np.asarray(features)
         print("[INFO] Learning the visual vocabulary with the following parameters:")
         print("   - Number of clusters:", n_clusters)
         print("   - Feature Extractor used:", self.feature_extractor.__class__.__name__)
         print("   - Dimension of the feature space:", feat_dim := features.shape[1])
-        if dim_reduction_factor:
-            print("   - New dimension after PCA reduction:", new_dim := feat_dim // dim_reduction_factor)
-            self._pca = PCA(n_components=new_dim)
-            self._pca.fit(features)
-            features = self._pca.transform(features)
-        if self.__class__.__name__ == "VLADEncoder":
-            model = KMeans(n_clusters=n_clusters, **kwargs)
-        elif self.__class__.__name__ == "FisherVectorEncoder":
-            model = GaussianMixture(n_components=n_clusters, **kwargs, covariance_type="diag")
-        else:
+        kind = DESC_F32
+        if rootsift:
+            kind = DESC_U8_ROOTSIFT if features.dtype == np.uint8 else DESC_F32_ROOTSIFT
+        if self.__class__.__name__ not in ("VLADEncoder", "FisherVectorEncoder"):
             raise ValueError("Unknown encoder class.")
-        model.fit(features)
-        self.clustering_model = model
+        rows = _learn.DeviceRows.from_host(self.context, features, kind)
+        reduced = None
+        try:
+            pca = None
+            if dim_reduction_factor:
+                print("   - New dimension after PCA reduction:", new_dim := feat_dim // dim_reduction_factor)
+                pca = _learn.fit_pca(rows, new_dim)
+                reduced = rows.transformed(pca)
+            data = reduced if reduced is not None else rows
+            if self.__class__.__name__ == "VLADEncoder":
+                model = _learn.fit_kmeans(data, n_clusters, **kwargs)
+            else:
+                model = _learn.fit_gmm(data, n_clusters, **kwargs)
+        finally:
+            rows.free()
+            if reduced is not None:
+                reduced.free()
+        # install the new tables: PCA first when the new model expects the reduced dimension
+        self._clustering_model = None
+        self._tables = None
+        if pca is not None:
+            self._pca = pca
+        self.clustering_model = model                          # the setter resets an incompatible older PCA, with a warning
 
     @_tupleize_first_arg
     def generate_encoding_map(self, image_paths: Iterable[str], /) -> dict[str, np.ndarray]:

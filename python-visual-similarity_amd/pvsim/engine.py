@@ -61,6 +61,45 @@ class PCATable(_Handle):
     C = Din = 0
 
 
+class DeviceBuffer:
+    """A block of device memory owned by a Context (pvs_malloc / pvs_free); .ptr is the raw device address."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self._ctx, self.nbytes, self.ptr = ctx, int(nbytes), 0
+        p = C.c_void_p()
+        check(_ffi.lib().pvs_malloc(ctx.handle, max(int(nbytes), 16), C.byref(p)))
+        self.ptr = int(p.value)
+
+    def upload(self, a: np.ndarray, offset: int = 0):
+        a = np.ascontiguousarray(a)
+        if offset + a.nbytes > self.nbytes:
+            raise ValueError("upload past the end of the device buffer")
+        check(_ffi.lib().pvs_memcpy_h2d(self._ctx.handle, C.c_void_p(self.ptr + offset), ptr(a), a.nbytes))
+        return self
+
+    def download(self, shape, dtype, offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        if offset + out.nbytes > self.nbytes:
+            raise ValueError("download past the end of the device buffer")
+        check(_ffi.lib().pvs_memcpy_d2h(self._ctx.handle, ptr(out), C.c_void_p(self.ptr + offset), out.nbytes))
+        return out
+
+    def fill_bytes(self, value: int):
+        check(_ffi.lib().pvs_memset(self._ctx.handle, C.c_void_p(self.ptr), int(value), self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr and self._ctx.handle is not None:
+            _ffi.lib().pvs_free(self._ctx.handle, C.c_void_p(self.ptr))
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Context:
     """One device + one stream.  `stream` may be a raw hipStream_t (int), e.g.
     torch.cuda.current_stream().cuda_stream, so that work interleaves with torch in order."""
@@ -264,6 +303,52 @@ class Context:
     def topk_merge_dev(self, d_idx_lists, d_val_lists, n_lists, nq, k, d_idx, d_val):
         check(_ffi.lib().pvs_topk_merge_dev(self.handle, ptr(d_idx_lists), ptr(d_val_lists), n_lists, nq, k, ptr(d_idx),
                                             ptr(d_val)))
+
+    # ------------------------------------------------------------------ vocabulary training (one device pass each)
+    def buffer(self, nbytes: int) -> "DeviceBuffer":
+        return DeviceBuffer(self, nbytes)
+
+    def materialise_dev(self, d_desc, kind, D, total_desc, d_out):
+        check(_ffi.lib().pvs_materialise_dev(self.handle, ptr(d_desc), kind, D, total_desc, ptr(d_out)))
+
+    def kmeans_step_dev(self, cb, d_x, total_desc, d_labels, d_prev_labels=None, d_sqdist=None):
+        """-> (residual sums (K, D) f64, counts (K,) f64, inertia, changed labels)"""
+        K, D = cb.K, cb.D
+        st = np.empty(K * D + K + 2, dtype=np.float64)
+        check(_ffi.lib().pvs_kmeans_step_dev(self.handle, cb.handle, ptr(d_x), total_desc, ptr(d_labels), ptr(d_prev_labels),
+                                             ptr(st), ptr(d_sqdist)))
+        return st[:K * D].reshape(K, D), st[K * D:K * D + K], float(st[K * D + K]), int(st[K * D + K + 1])
+
+    def gmm_em_step_dev(self, g, d_x, total_desc):
+        """-> (s0 (K,), s1 (K, D), s2 (K, D), sum_i log p(x_i)), all fp64"""
+        K, D = g.K, g.D
+        st = np.empty(K + 2 * K * D + 1, dtype=np.float64)
+        check(_ffi.lib().pvs_gmm_em_step_dev(self.handle, g.handle, ptr(d_x), total_desc, ptr(st)))
+        s12 = st[K:K + 2 * K * D].reshape(K, 2, D)
+        return st[:K], s12[:, 0, :], s12[:, 1, :], float(st[-1])
+
+    def gram_dev(self, d_x, D, total_desc):
+        """-> (sum_i x_i (D,), sum_i x_i x_i^T (D, D)) in fp64"""
+        out = np.empty(D + D * D, dtype=np.float64)
+        check(_ffi.lib().pvs_gram_dev(self.handle, ptr(d_x), D, total_desc, ptr(out)))
+        return out[:D], out[D:].reshape(D, D)
+
+    def label_sums_dev(self, d_x, D, total_desc, d_labels, K, square=False):
+        out = np.empty((K, D), dtype=np.float64)
+        check(_ffi.lib().pvs_label_sums_dev(self.handle, ptr(d_x), D, total_desc, ptr(d_labels), K, int(square), ptr(out)))
+        return out
+
+    def seed_distances_dev(self, d_x, D, total_desc, cand, d_mind, d_dist):
+        cand = np.ascontiguousarray(cand, dtype=np.float32).reshape(-1, D)
+        pot = np.empty(cand.shape[0], dtype=np.float64)
+        check(_ffi.lib().pvs_seed_distances_dev(self.handle, ptr(d_x), D, total_desc, ptr(cand), cand.shape[0], ptr(d_mind),
+                                                ptr(d_dist), ptr(pot)))
+        return pot
+
+    def min_update_dev(self, d_mind, d_dist, total_desc):
+        bs = np.empty((total_desc + 4095) // 4096, dtype=np.float64)
+        check(_ffi.lib().pvs_min_update_dev(self.handle, ptr(d_mind), ptr(d_dist), total_desc, ptr(bs)))
+        return bs
 
     # ------------------------------------------------------------------ timers
     def timers_enable(self, on=True):

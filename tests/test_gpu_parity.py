@@ -480,3 +480,143 @@ def test_deep_conv_feature_extractor_and_fisher_end_to_end():
     assert f.shape == (3, K + 2 * K * D) and f.dtype == np.float64
     ref = orc.fisher_encode([fx(im) for im in imgs], gm.weights_, gm.means_, gm.covariances_)
     np.testing.assert_allclose(f, ref, rtol=0, atol=1e-7)        # extractor output re-computed per call (conv noise)
+
+
+# ======================================================================================= learn() on the device
+# Tolerances: the reference's fits (scikit-learn) accumulate k-means sums in fp32 per thread chunk and PCA's covariance
+# in fp32; the device forms them in fp64.  Labels must agree exactly; centres to 5e-4 abs (values up to 16, i.e. ~3e-5
+# relative); GMM tables (fp64 on both sides) to 1e-9 relative; PCA axes to 2e-3 (the golden itself is fp32 noisy).
+KM_ATOL = 5e-4
+
+
+def _learn_rows(ctx, g):
+    from pvsim import learn
+    return learn.DeviceRows.from_host(ctx, g["x_u8"].astype(np.float32) / np.float32(16.0))
+
+
+def test_learn_kmeans_matches_reference_fit(gpu_ctx):
+    from pvsim import learn
+    g = load_golden("learn_k16_d32")
+    rows = _learn_rows(gpu_ctx, g)
+    m = learn.fit_kmeans(rows, 16, init=g["c0"], n_init=1, max_iter=3, tol=0.0)
+    assert m.n_iter_ == int(g["km3_n_iter"]) and np.array_equal(m.labels_, g["km3_labels"])
+    np.testing.assert_allclose(m.cluster_centers_, g["km3_centers"], rtol=0, atol=KM_ATOL)
+    assert abs(m.inertia_ - float(g["km3_inertia"])) <= 2e-5 * float(g["km3_inertia"])
+    m = learn.fit_kmeans(rows, 16, init=g["c0"], n_init=1)               # default stopping rule
+    assert m.n_iter_ == int(g["km_n_iter"]) and np.array_equal(m.labels_, g["km_labels"])
+    np.testing.assert_allclose(m.cluster_centers_, g["km_centers"], rtol=0, atol=KM_ATOL)
+    # and against the restatement run here on the same start
+    c, l, inertia, n_it = orc.kmeans_lloyd(g["x_u8"].astype(np.float32) / 16, g["c0"])
+    assert n_it == m.n_iter_ and np.array_equal(l, m.labels_)
+    # run-to-run identical
+    m2 = learn.fit_kmeans(rows, 16, init=g["c0"], n_init=1)
+    assert np.array_equal(m2.cluster_centers_, m.cluster_centers_) and m2.inertia_ == m.inertia_
+    rows.free()
+
+
+def test_learn_gmm_matches_reference_fit(gpu_ctx):
+    from pvsim import learn
+    g = load_golden("learn_k16_d32")
+    rows = _learn_rows(gpu_ctx, g)
+    kw = dict(weights_init=g["g_w0"], means_init=g["g_m0"], precisions_init=g["g_p0"])
+    with pytest.warns(UserWarning):                                        # tol=0 never converges, as in scikit-learn
+        m = learn.fit_gmm(rows, 8, max_iter=5, tol=0.0, **kw)
+    assert m.n_iter_ == 5 and not m.converged_
+    np.testing.assert_allclose(m.weights_, g["g5_weights"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(m.means_, g["g5_means"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(m.covariances_, g["g5_cov"], rtol=1e-9, atol=1e-11)
+    assert abs(m.lower_bound_ - float(g["g5_lower"])) < 1e-10
+    m = learn.fit_gmm(rows, 8, **kw)
+    assert m.converged_ == bool(g["g_converged"]) and m.n_iter_ == int(g["g_n_iter"])
+    np.testing.assert_allclose(m.means_, g["g_means"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(m.covariances_, g["g_cov"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(m.weights_, g["g_weights"], rtol=1e-9, atol=1e-13)
+    rows.free()
+
+
+def test_learn_pca_matches_reference_fit(gpu_ctx):
+    from pvsim import learn
+    g = load_golden("learn_k16_d32")
+    rows = _learn_rows(gpu_ctx, g)
+    m = learn.fit_pca(rows, 16)
+    x = g["x_u8"].astype(np.float64) / 16
+    np.testing.assert_allclose(m.mean_, g["pca_mean"], rtol=0, atol=2e-5)
+    c64, mean64, ev64 = orc.pca_fit(x, 16)                                 # the same procedure in fp64: tight
+    np.testing.assert_allclose(np.abs(np.sum(m.components_.astype(np.float64) * c64, axis=1)), 1.0, atol=1e-6)
+    np.testing.assert_allclose(m.explained_variance_, ev64, rtol=1e-9)
+    cos = np.sum(m.components_.astype(np.float64) * g["pca_components"].astype(np.float64), axis=1)
+    assert np.all(cos > 1 - 2e-3), cos                                     # same axes AND same signs as the reference's fit
+    np.testing.assert_allclose(m.explained_variance_, g["pca_explained_variance"], rtol=2e-3)
+    # transform on the device with the fitted table
+    red = rows.transformed(m)
+    got = red.buf.download((rows.n, 16), np.float32)
+    np.testing.assert_allclose(got, orc.pca_transform(x.astype(np.float32), m.components_, m.mean_), rtol=0, atol=2e-4)
+    red.free()
+    rows.free()
+
+
+def test_learn_seeding_and_label_sums(gpu_ctx):
+    from pvsim import learn
+    g = load_golden("learn_k16_d32")
+    x = g["x_u8"].astype(np.float32) / np.float32(16.0)
+    rows = _learn_rows(gpu_ctx, g)
+    c1, i1 = learn.kmeans_plusplus(rows, 16, random_state=3)
+    c2, i2 = learn.kmeans_plusplus(rows, 16, random_state=3)
+    assert np.array_equal(i1, i2) and np.array_equal(c1, c2) and len(set(i1.tolist())) == 16
+    assert np.array_equal(c1, x[i1])
+    # seeded k-means++ start + Lloyd reaches an inertia close to the reference's fit from its own start
+    m = learn.fit_kmeans(rows, 16, random_state=3)
+    assert m.inertia_ < 1.05 * float(g["km_inertia"])
+    # potentials: sum_i min(mind, d_j) against NumPy
+    cand = x[[5, 77, 4000]]
+    dist = gpu_ctx.buffer(3 * rows.n * 4)
+    pot = gpu_ctx.seed_distances_dev(rows.ptr, 32, rows.n, cand, None, dist.ptr)
+    d = ((x[None, :, :].astype(np.float64) - cand[:, None, :]) ** 2).sum(-1)
+    np.testing.assert_allclose(pot, d.sum(1), rtol=1e-6)
+    np.testing.assert_allclose(dist.download((3, rows.n), np.float32), d, rtol=2e-6, atol=1e-6)
+    # per-label sums
+    lab = gpu_ctx.buffer(rows.n * 4).upload(m.labels_)
+    s1 = gpu_ctx.label_sums_dev(rows.ptr, 32, rows.n, lab.ptr, 16, square=False)
+    s2 = gpu_ctx.label_sums_dev(rows.ptr, 32, rows.n, lab.ptr, 16, square=True)
+    r1, r2 = np.zeros((16, 32)), np.zeros((16, 32))
+    np.add.at(r1, m.labels_, x.astype(np.float64))
+    np.add.at(r2, m.labels_, (x * x).astype(np.float64))
+    np.testing.assert_allclose(s1, r1, rtol=5e-6)       # fp32 sums inside a 4096-descriptor chunk, fp64 across chunks
+    np.testing.assert_allclose(s2, r2, rtol=5e-6)
+    # GMM from the k-means start (scikit-learn's default init_params): a valid mixture at least as good as the golden's
+    gm = learn.fit_gmm(rows, 8, random_state=0)
+    assert abs(gm.weights_.sum() - 1) < 1e-12 and np.all(gm.covariances_ > 0) and gm.converged_
+    assert gm.lower_bound_ > float(g["g_lower"]) - 1.0
+    for b in (dist, lab):
+        b.free()
+    rows.free()
+
+
+def test_learn_through_the_encoder_api(tables):
+    """VLADEncoder.learn / FisherVectorEncoder.learn as the reference calls them (keyword arguments of the scikit-learn
+    estimators), including dim_reduction_factor, then encode with the learnt vocabulary."""
+    from pvsim.encoders import VLADEncoder, FisherVectorEncoder
+    from pvsim.features import Lambda
+    from pvsim.models import KMeansModel, GMMModel
+    g = load_golden("learn_k16_d32")
+    xu8 = g["x_u8"]
+    images = [xu8[i * 500:(i + 1) * 500].astype(np.int64) for i in range(40)]
+    fx = Lambda(lambda im: im.astype(np.float32) / np.float32(16.0), 32)
+    enc = VLADEncoder(fx, kmeans_model=KMeansModel(g["c0"]))
+    enc.learn(images, n_clusters=16, init=g["c0"], n_init=1, max_iter=3, tol=0.0)
+    np.testing.assert_allclose(enc.clustering_model.cluster_centers_, g["km3_centers"], rtol=0, atol=KM_ATOL)
+    v = enc.encode(images[:3])
+    want = orc.vlad_encode([fx(im) for im in images[:3]], enc.clustering_model.cluster_centers_)
+    np.testing.assert_allclose(v, want, rtol=0, atol=VLAD_ATOL)
+    enc.learn(images, n_clusters=16, dim_reduction_factor=2, n_init=1, random_state=0, max_iter=5)
+    assert enc.pca is not None and enc.pca.n_components == 16 and enc.clustering_model.n_features_in_ == 16
+    assert enc.encode(images[:2]).shape == (2, 16 * 16)
+    with pytest.raises(TypeError):
+        enc.learn(images, n_clusters=16, not_a_kmeans_argument=1)
+    fe = FisherVectorEncoder(fx, gmm_model=GMMModel(np.full(8, 1 / 8), g["g_m0"], 1 / g["g_p0"]))
+    fe.learn(images, n_clusters=8, weights_init=g["g_w0"], means_init=g["g_m0"], precisions_init=g["g_p0"])
+    np.testing.assert_allclose(fe.clustering_model.means_, g["g_means"], rtol=1e-9, atol=1e-11)
+    f = fe.encode(images[:2])
+    want = orc.fisher_encode([fx(im) for im in images[:2]], fe.clustering_model.weights_, fe.clustering_model.means_,
+                             fe.clustering_model.covariances_)
+    np.testing.assert_allclose(f, want, rtol=0, atol=FISHER_ATOL)

@@ -219,3 +219,26 @@ def test_c_oracle_variants_and_retrieval(tables):
     idx, val = orc_c.retrieve(qv, dbv, 7)
     assert np.array_equal(idx, g["top7_index"])
     np.testing.assert_allclose(val, g["top7_score"], atol=5e-7)
+
+
+def test_learn_restatement_matches_the_reference_fits():
+    """learn(): the restated PCA / Lloyd / EM procedures against the tables the reference's own learn() fitted
+    (tests/golden/make_golden_learn.py)."""
+    g = load_golden("learn_k16_d32")
+    x = g["x_u8"].astype(np.float32) / np.float32(16.0)
+    for tag, kw in (("km3", dict(max_iter=3, tol=0.0)), ("km", {})):
+        c, labels, inertia, n_iter = orc.kmeans_lloyd(x, g["c0"], **kw)
+        assert n_iter == int(g[tag + "_n_iter"]) and np.array_equal(labels, g[tag + "_labels"])
+        np.testing.assert_allclose(c, g[tag + "_centers"], rtol=0, atol=5e-4)      # fp32 member sums, order differs
+        assert abs(inertia - float(g[tag + "_inertia"])) <= 2e-5 * inertia
+    comp, mean, ev = orc.pca_fit(x, 16)
+    assert np.array_equal(comp, g["pca_components"]) and np.array_equal(mean, g["pca_mean"])
+    np.testing.assert_allclose(ev, g["pca_explained_variance"], rtol=1e-6)
+    w, mu, cov, lower, n_iter, conv = orc.gmm_em(x, g["g_w0"], g["g_m0"], 1.0 / g["g_p0"], max_iter=5, tol=0.0)
+    assert n_iter == 5 and not conv and abs(lower - float(g["g5_lower"])) < 1e-11
+    for a, b in ((w, "g5_weights"), (mu, "g5_means"), (cov, "g5_cov")):
+        np.testing.assert_allclose(a, g[b], rtol=1e-10, atol=1e-12)
+    w, mu, cov, lower, n_iter, conv = orc.gmm_em(x, g["g_w0"], g["g_m0"], 1.0 / g["g_p0"])
+    assert n_iter == int(g["g_n_iter"]) and conv == bool(g["g_converged"])
+    for a, b in ((w, "g_weights"), (mu, "g_means"), (cov, "g_cov")):
+        np.testing.assert_allclose(a, g[b], rtol=1e-10, atol=1e-12)
