@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--images", type=int, default=8189)
     ap.add_argument("--desc", choices=["f32", "u8"], default="f32",
                     help="descriptor rows in HBM: fp32 RootSIFT (default) or raw uint8 SIFT with fused RootSIFT")
-    ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim"], default="config2",
+    ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim", "learn"], default="config2",
                     help="config2 = the headline line (default).  Side workloads (single GPU, same JSON shape, not the "
                          "headline): fisher = BASELINE configs[2] (Fisher D=512 K=256 n=196), vlad512 = the per-GPU share of "
                          "configs[3] (n=512 descriptors per image, encode only), fp16sim = configs[4] scaled to one GPU "
@@ -197,6 +197,53 @@ def side_workload(args):
                                  "frac": round(2.0 * N * n * K_CLUSTERS * DIM / (st["assign"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                  "traffic": None},
                     "encode_algorithmic_GBps": round(byt / dt / 1e9, 1)})
+    elif args.workload == "learn":
+        # vocabulary training: one "step" = k-means++ seeding + 10 Lloyd iterations (K=256)
+        # and 5 EM iterations of a K=256 diagonal GMM over args.images x 64 RootSIFT descriptors
+        from pvsim import learn
+        n_img = min(N, 16384)
+        raw, offsets = make_corpus(n_img, 1238, dev)
+        total = min(int(offsets[-1]), n_img * 64)
+        x = rootsift_torch(raw[:total]).contiguous()
+        rows = learn.DeviceRows.from_device(ctx, x.data_ptr(), total, DIM)
+        torch.cuda.synchronize()
+        res = {}
+
+        def one():
+            t0 = time.perf_counter()
+            c0, _ = learn.kmeans_plusplus(rows, K_CLUSTERS, random_state=0)
+            t1 = time.perf_counter()
+            km = learn.fit_kmeans(rows, K_CLUSTERS, init=c0, n_init=1, max_iter=10, tol=0.0)
+            t2 = time.perf_counter()
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                gm = learn.fit_gmm(rows, K_CLUSTERS, weights_init=np.full(K_CLUSTERS, 1.0 / K_CLUSTERS), means_init=km.cluster_centers_,
+                                   precisions_init=np.full((K_CLUSTERS, DIM), 1.0 / 2e-3), max_iter=5, tol=0.0)
+            t3 = time.perf_counter()
+            pca = learn.fit_pca(rows, 64)
+            t4 = time.perf_counter()
+            res.update(seeding_s=t1 - t0, lloyd10_s=t2 - t1, em5_s=t3 - t2, pca_s=t4 - t3, inertia=km.inertia_, lower_bound=gm.lower_bound_)
+
+        dt, st = timed(one)
+        out.update({"metric": "descriptors/sec through k-means++ seeding + 10 Lloyd iterations + 5 EM iterations + PCA fit (K=256, D=128)",
+                    "value": round(total / dt, 1), "unit": "descriptors/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "f32 (k-means), f64 (EM, PCA)",
+                    "scaling": "strong", "stages_ms_per_step": st, "phases_s": {k: round(v, 4) for k, v in res.items()},
+                    "config": {"workload": f"{total} RootSIFT descriptors x {DIM}, K = {K_CLUSTERS}"}})
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            import pvsim_oracle as orc
+            sub = x[:100000].cpu().numpy()
+            c0 = sub[:K_CLUSTERS].copy()
+            t0 = time.perf_counter()
+            orc.kmeans_lloyd(sub, c0, max_iter=2, tol=0.0)
+            t_l = (time.perf_counter() - t0) / 2 / len(sub)
+            t0 = time.perf_counter()
+            orc.gmm_em(sub, np.full(K_CLUSTERS, 1.0 / K_CLUSTERS), c0, np.full((K_CLUSTERS, DIM), 2e-3), max_iter=1, tol=0.0)
+            t_e = (time.perf_counter() - t0) / len(sub)
+            out["cpu_baseline"] = {"value": round(1.0 / (10 * t_l + 5 * t_e), 1), "unit": "descriptors/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "NumPy restatement (BLAS threads as configured): 2 Lloyd + 1 EM iteration on 100000 descriptors, "
+                                             "scaled to 10 + 5 iterations; seeding and PCA not included"}
     else:  # fp16sim
         L, k = K_CLUSTERS * DIM, 10
         # VLAD-like rows: 256 unit-norm 128-d blocks, ~35 % of them empty

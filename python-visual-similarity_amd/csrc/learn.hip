@@ -310,49 +310,69 @@ int launch_gram(pvs_ctx* ctx, const float* x, int64_t total, int D, double* d_ou
 // d_mind null = no centre chosen yet (potential = plain sum of distances).
 constexpr int SEED_MAX = 8;
 
+constexpr int SEED_ROWS = 1024;  // descriptors per block (16 rounds of 64)
+
 __global__ __launch_bounds__(256) void learn_seed_kernel(const float* __restrict__ X, int64_t total, int D, const float* __restrict__ cand,
                                                          int nc, const float* __restrict__ mind, float* __restrict__ dist,
-                                                         double* __restrict__ block_pot /*[nblk][SEED_MAX]*/) {
+                                                         double* __restrict__ block_pot /*[SEED_MAX][nblk]*/) {
   extern __shared__ float sc[];  // [nc][D] candidates, then [64][SEED_MAX] row results
   float* res = sc + nc * D;
   for (int i = threadIdx.x; i < nc * D; i += 256) sc[i] = cand[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r0 = (int64_t)blockIdx.x * 64;
-  for (int j = 0; j < 16; ++j) {
-    const int64_t row = r0 + wave * 16 + j;
-    float s[SEED_MAX];
+  double pot = 0.0;  // thread c < SEED_MAX: this block's potential for candidate c, rows in order
+  for (int round = 0; round < SEED_ROWS / 64; ++round) {
+    const int64_t r0 = (int64_t)blockIdx.x * SEED_ROWS + round * 64;
+    if (r0 >= total) break;
+    for (int j = 0; j < 16; ++j) {
+      const int64_t row = r0 + wave * 16 + j;
+      float s[SEED_MAX];
 #pragma unroll
-    for (int c = 0; c < SEED_MAX; ++c) s[c] = 0.f;
-    if (row < total) {
-      for (int d = lane; d < D; d += 64) {
-        const float xv = X[row * D + d];
+      for (int c = 0; c < SEED_MAX; ++c) s[c] = 0.f;
+      if (row < total) {
+        for (int d = lane; d < D; d += 64) {
+          const float xv = X[row * D + d];
 #pragma unroll
-        for (int c = 0; c < SEED_MAX; ++c)
-          if (c < nc) {
-            const float t = xv - sc[c * D + d];
-            s[c] = fmaf(t, t, s[c]);
-          }
+          for (int c = 0; c < SEED_MAX; ++c)
+            if (c < nc) {
+              const float t = xv - sc[c * D + d];
+              s[c] = fmaf(t, t, s[c]);
+            }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < SEED_MAX; ++c)
+        for (int m = 32; m >= 1; m >>= 1) s[c] += __shfl_xor(s[c], m, 64);
+      if (lane == 0) {
+        const float md = (row < total && mind != nullptr) ? mind[row] : INFINITY;
+#pragma unroll
+        for (int c = 0; c < SEED_MAX; ++c) {
+          if (c < nc && row < total) dist[(int64_t)c * total + row] = s[c];
+          res[(wave * 16 + j) * SEED_MAX + c] = (c < nc && row < total) ? fminf(md, s[c]) : 0.f;
+        }
       }
     }
-#pragma unroll
-    for (int c = 0; c < SEED_MAX; ++c)
-      for (int m = 32; m >= 1; m >>= 1) s[c] += __shfl_xor(s[c], m, 64);
-    if (lane == 0) {
-      const float md = (row < total && mind != nullptr) ? mind[row] : INFINITY;
-#pragma unroll
-      for (int c = 0; c < SEED_MAX; ++c) {
-        if (c < nc && row < total) dist[(int64_t)c * total + row] = s[c];
-        res[(wave * 16 + j) * SEED_MAX + c] = (c < nc && row < total) ? fminf(md, s[c]) : 0.f;
-      }
-    }
+    __syncthreads();
+    if (threadIdx.x < SEED_MAX)
+      for (int j = 0; j < 64; ++j) pot += (double)res[j * SEED_MAX + threadIdx.x];
+    __syncthreads();
   }
+  if (threadIdx.x < SEED_MAX) block_pot[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = pot;
+}
+
+// block c: d_pot[c] = sum of block_pot[c][0..nblk)  (strided partial sums, fixed tree)
+__global__ __launch_bounds__(256) void learn_seed_reduce_kernel(const double* __restrict__ block_pot, int64_t nblk, double* __restrict__ pot) {
+  __shared__ double sh[256];
+  const double* v = block_pot + (int64_t)blockIdx.x * nblk;
+  double t = 0.0;
+  for (int64_t i = threadIdx.x; i < nblk; i += 256) t += v[i];
+  sh[threadIdx.x] = t;
   __syncthreads();
-  if (threadIdx.x < SEED_MAX) {
-    double t = 0.0;
-    for (int j = 0; j < 64; ++j) t += (double)res[j * SEED_MAX + threadIdx.x];
-    block_pot[(int64_t)blockIdx.x * SEED_MAX + threadIdx.x] = t;
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) pot[blockIdx.x] = sh[0];
 }
 
 int launch_seed_distances(pvs_ctx* ctx, const float* x, int64_t total, int D, const float* d_cand, int n_cand,
@@ -361,12 +381,11 @@ int launch_seed_distances(pvs_ctx* ctx, const float* x, int64_t total, int D, co
   if (total <= 0) PVS_FAIL(PVS_ERR_INVALID, "seeding needs at least one descriptor");
   const size_t lds = ((size_t)n_cand * D + 64 * SEED_MAX) * 4;
   if (lds > 64 * 1024) PVS_FAIL(PVS_ERR_UNSUPPORTED, "descriptor dimension %d too large for the seeding kernel", D);
-  const int64_t nblk = (total + 63) / 64;
+  const int64_t nblk = (total + SEED_ROWS - 1) / SEED_ROWS;
   double* bp = nullptr;
   PVS_TRY(ws_reserve(ctx, 1, (size_t)nblk * SEED_MAX * 8, reinterpret_cast<void**>(&bp)));
   hipLaunchKernelGGL(learn_seed_kernel, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, x, total, D, d_cand, n_cand, d_mind, d_dist, bp);
-  // block_pot is [nblk][SEED_MAX]: "chunks" = blocks, len = SEED_MAX
-  hipLaunchKernelGGL(learn_reduce_f64_kernel, dim3(1), dim3(256), 0, ctx->stream, bp, nblk, (int64_t)SEED_MAX, d_pot, 1);
+  hipLaunchKernelGGL(learn_seed_reduce_kernel, dim3(SEED_MAX), dim3(256), 0, ctx->stream, bp, nblk, d_pot);
   PVS_HIP(hipGetLastError());
   return PVS_OK;
 }

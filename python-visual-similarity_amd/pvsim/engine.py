@@ -70,6 +70,13 @@ class DeviceBuffer:
         check(_ffi.lib().pvs_malloc(ctx.handle, max(int(nbytes), 16), C.byref(p)))
         self.ptr = int(p.value)
 
+    @classmethod
+    def view(cls, ctx: "Context", dptr: int, nbytes: int) -> "DeviceBuffer":
+        """Non-owning view of device memory allocated elsewhere (e.g. torch.Tensor.data_ptr()); free() is a no-op."""
+        b = cls.__new__(cls)
+        b._ctx, b.nbytes, b.ptr, b._borrowed = ctx, int(nbytes), int(dptr), True
+        return b
+
     def upload(self, a: np.ndarray, offset: int = 0):
         a = np.ascontiguousarray(a)
         if offset + a.nbytes > self.nbytes:
@@ -89,7 +96,7 @@ class DeviceBuffer:
         return self
 
     def free(self):
-        if self.ptr and self._ctx.handle is not None:
+        if self.ptr and not getattr(self, "_borrowed", False) and self._ctx.handle is not None:
             _ffi.lib().pvs_free(self._ctx.handle, C.c_void_p(self.ptr))
         self.ptr = 0
 

@@ -62,6 +62,12 @@ class DeviceRows:
             stage.free()
         return cls(ctx, n, D, out)
 
+    @classmethod
+    def from_device(cls, ctx: Context, dptr: int, n: int, D: int) -> "DeviceRows":
+        """Rows that already live on the device as contiguous fp32 (n, D), e.g. a torch tensor's data_ptr(); not owned."""
+        from .engine import DeviceBuffer
+        return cls(ctx, n, D, DeviceBuffer.view(ctx, dptr, int(n) * int(D) * 4))
+
     def row(self, i: int) -> np.ndarray:
         return self.buf.download((self.D,), np.float32, offset=int(i) * self.D * 4)
 
