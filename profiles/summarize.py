@@ -43,7 +43,7 @@ for k, d in out.items():
         d["hbm_bytes_per_launch_corrected"] = (2.0 * f_ + w_) * 1024.0
 if out:
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
-                          "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+                          "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
                "note": "FETCH_SIZE doubled per the gfx950 correction; Infinity-Cache hits are included in these "
                        "fabric-side counters, so this is traffic beyond L2, an upper bound on HBM bytes",
                "kernels": out}, open(f"profiles/{tag}_pmc_hbm.json", "w"), indent=1)
