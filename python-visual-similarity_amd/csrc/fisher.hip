@@ -15,6 +15,7 @@
 // (MI355X runs fp64 at half the fp32 rate -- cheaper than losing 3 digits).  K <= 256 runs on v_mfma_f64_16x16x4
 // (posterior as one GEMM over [x | x**2], moments as gamma^T [x | x**2]); larger K uses the vector-FMA kernels.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.hpp"
 #include "desc_load.hpp"
@@ -400,8 +401,32 @@ __device__ __forceinline__ void store_out(void* out, int f64, int64_t i, T v) {
 
 constexpr int MM_THREADS = 512, MM_DIMS = 64;
 
+// The fused epilogue is instantiated per (power, norm) case: with p and the norm order as run-time values every one of
+// its 64 unrolled outputs carried an inlined pow() (18k instructions, 110 KB of code -- twice the instruction cache --
+// and the kernel ran at 2.3x the time of its own MFMA loop).  PM: 0 p == 1, 1 p == 0.5, 2 any p.  NM: 2 L2, 1 abs-based
+// (L1 / inf), 0 general order.  The general cases call out-of-line helpers.
+__device__ __attribute__((noinline)) double power_norm64_slow(double v, double p);
+__device__ __attribute__((noinline)) double norm_pow64_slow(double av, double p);
+template <int PM>
+__device__ __forceinline__ double pnorm_t(double v, double p) {
+  if constexpr (PM == 0) {
+    return v;
+  } else if constexpr (PM == 1) {
+    const double m = sqrt(fabs(v));
+    return v > 0.0 ? m : (v < 0.0 ? -m : (v == 0.0 ? 0.0 * m : v));
+  } else {
+    return power_norm64_slow(v, p);
+  }
+}
+template <int NM>
+__device__ __forceinline__ double nterm_t(double v, double p) {
+  if constexpr (NM == 2) return v * v;
+  else if constexpr (NM == 1) return fabs(v);
+  else return norm_pow64_slow(fabs(v), p);
+}
+
 // RAW = leave the sums as they are (one EM M-step's sufficient statistics per descriptor chunk) instead of the Fisher epilogue
-template <bool RAW>
+template <bool RAW, int PM = 2, int NM = 0, bool OUT64 = true>
 __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomMArgs a) {
   __shared__ double la[256 * F64_KCP];   // gamma^T chunk: [k][i]
   __shared__ double lb[128 * F64_KCP];   // Z chunk:       [c][i], c = 64 wn + (x: 0..31 | x**2: 32..63)
@@ -473,6 +498,9 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
   // Epilogue arithmetic: fp64 divisions and square roots cost tens of instructions each, and this epilogue is as long
   // as the MFMA loop if written literally.  The per-(k,d) divisors 1/(sqrt(w) sqrt(cov)) and 1/(sqrt(2) sqrt(w) cov)
   // come from tables built once per GMM, and /n becomes *(1/n): <= 2 ulp of fp64 from the literal formula.
+  using OutT = std::conditional_t<OUT64, double, float>;
+  OutT* const out = static_cast<OutT*>(a.out) + (int64_t)img * L;
+  const bool is_max = a.norm_mode == 3;
   double part = 0.0;
   const int col = lane & 15, rq = lane >> 4;
   const double dn = (double)(n > 0 ? n : 1), rdn = 1.0 / dn;
@@ -481,48 +509,44 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = wm * 64 + 16 * mi + 4 * r + rq;
-      if (k >= K) continue;
-      const double pp_sum = s0s[k] * rdn;
+      const double pp_sum = s0s[k < K ? k : 0] * rdn;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int d = d0 + 16 * ni + col;
-        if (d >= D) continue;
-        const int64_t o_mu = (int64_t)img * L + K + (int64_t)k * D + d, o_sg = o_mu + (int64_t)K * D;
-        if (n == 0) {   // empty image: zero row (the reference divides by zero; fenced quirk)
-          store_out(a.out, a.out_f64, o_mu, 0.0);
-          store_out(a.out, a.out_f64, o_sg, 0.0);
-          continue;
-        }
-        const int64_t kd_i = (int64_t)k * D + d;
-        const double mu = a.mu[kd_i], cv = a.cov[kd_i];
+        const bool live = k < K && d < D;
+        const int64_t kd_i = live ? (int64_t)k * D + d : 0;      // clamped: the loads below are unconditional
+        const double mu = a.mu[kd_i], cv = a.cov[kd_i], imu = a.inv_mu[kd_i], isg = a.inv_sg[kd_i];
         const double pp_x = acc[mi][ni][r] * rdn, pp_x2 = acc[mi][ni + 2][r] * rdn;
         double d_mu = pp_x - pp_sum * mu;
         double d_sg = ((-pp_x2 - pp_sum * (mu * mu)) + pp_sum * cv) + (2.0 * pp_x) * mu;
-        d_mu = power_norm64(d_mu * a.inv_mu[kd_i], a.power);
-        d_sg = power_norm64(d_sg * a.inv_sg[kd_i], a.power);
-        store_out(a.out, a.out_f64, o_mu, d_mu);
-        store_out(a.out, a.out_f64, o_sg, d_sg);
-        const double t1 = norm_term64(d_mu, a.norm_mode, a.norm_p), t2 = norm_term64(d_sg, a.norm_mode, a.norm_p);
-        part = a.norm_mode == 3 ? fmax(part, fmax(t1, t2)) : part + (t1 + t2);
+        d_mu = pnorm_t<PM>(d_mu * imu, a.power);
+        d_sg = pnorm_t<PM>(d_sg * isg, a.power);
+        if (n == 0) d_mu = d_sg = 0.0;   // empty image: zero row (the reference divides by zero; fenced quirk)
+        if (live) {
+          out[K + kd_i] = (OutT)d_mu;
+          out[K + (int64_t)K * D + kd_i] = (OutT)d_sg;
+          const double t1 = nterm_t<NM>(d_mu, a.norm_p), t2 = nterm_t<NM>(d_sg, a.norm_p);
+          part = is_max ? fmax(part, fmax(t1, t2)) : part + (t1 + t2);
+        }
       }
     }
   if (blockIdx.x == 0 && tid < K) {   // d_pi (fisher_vector.py:107,117)
     const double w = a.w[tid];
-    const double d_pi = n > 0 ? power_norm64((s0s[tid] / dn - w) / sqrt(w), a.power) : 0.0;
-    store_out(a.out, a.out_f64, (int64_t)img * L + tid, d_pi);
-    const double t = norm_term64(d_pi, a.norm_mode, a.norm_p);
-    part = a.norm_mode == 3 ? fmax(part, t) : part + t;
+    const double d_pi = n > 0 ? pnorm_t<PM>((s0s[tid] / dn - w) / sqrt(w), a.power) : 0.0;
+    out[tid] = (OutT)d_pi;
+    const double t = nterm_t<NM>(d_pi, a.norm_p);
+    part = is_max ? fmax(part, t) : part + t;
   }
   // deterministic block reduction of the norm term
   for (int m = 32; m >= 1; m >>= 1) {
     const double o = __shfl_xor(part, m, 64);
-    part = a.norm_mode == 3 ? fmax(part, o) : part + o;
+    part = is_max ? fmax(part, o) : part + o;
   }
   if (lane == 0) red[wave] = part;
   __syncthreads();
   if (tid == 0) {
     double t = red[0];
-    for (int wv = 1; wv < 8; ++wv) t = a.norm_mode == 3 ? fmax(t, red[wv]) : t + red[wv];
+    for (int wv = 1; wv < 8; ++wv) t = is_max ? fmax(t, red[wv]) : t + red[wv];
     a.partial[(int64_t)img * a.dblocks + blockIdx.x] = t;
   }
 }
@@ -561,6 +585,8 @@ __device__ __forceinline__ double norm_term64(double v, int mode, double p) {
   const double av = fabs(v);
   return mode == 2 ? v * v : (mode == 0 ? pow(av, p) : av);
 }
+__device__ __attribute__((noinline)) double power_norm64_slow(double v, double p) { return power_norm64(v, p); }
+__device__ __attribute__((noinline)) double norm_pow64_slow(double av, double p) { return pow(av, p); }
 
 // PRE = false: the sums are accumulated here with vector fp64 FMAs (any K);  PRE = true: the sums were produced by
 // the fp64-MFMA kernels and this kernel is only the gradient / power-norm / norm-partial epilogue.
@@ -771,7 +797,22 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
   if (mfma) {
     MomMArgs m{x, D, ld, K, d_offsets + img0, resp_abs, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, prm.power_norm_weight, norm_mode, ord,
                out_b, out_f64, partial, dblocks, nullptr, nullptr};
-    hipLaunchKernelGGL(fisher_moments_mfma_kernel<false>, dim3((unsigned)dblocks, (unsigned)n_img), dim3(MM_THREADS), 0, ctx->stream, m);
+    const int pm = prm.power_norm_weight == 1.0 ? 0 : (prm.power_norm_weight == 0.5 ? 1 : 2);
+    const int nm = norm_mode == 2 ? 2 : (norm_mode == 0 ? 0 : 1);
+    const dim3 grid((unsigned)dblocks, (unsigned)n_img), blk(MM_THREADS);
+#define PVS_MOM(PMV, NMV)                                                                                             \
+  do {                                                                                                                \
+    if (out_f64) hipLaunchKernelGGL((fisher_moments_mfma_kernel<false, PMV, NMV, true>), grid, blk, 0, ctx->stream, m); \
+    else hipLaunchKernelGGL((fisher_moments_mfma_kernel<false, PMV, NMV, false>), grid, blk, 0, ctx->stream, m);        \
+  } while (0)
+    if (pm == 1 && nm == 2) PVS_MOM(1, 2);        // the reference's defaults: p = 0.5, L2
+    else if (pm == 0 && nm == 2) PVS_MOM(0, 2);
+    else if (pm == 1 && nm == 1) PVS_MOM(1, 1);
+    else if (pm == 0 && nm == 1) PVS_MOM(0, 1);
+    else if (nm == 2) PVS_MOM(2, 2);
+    else if (nm == 1) PVS_MOM(2, 1);
+    else PVS_MOM(2, 0);
+#undef PVS_MOM
   } else {
     MomArgs a{};
     a.X = x; a.D = D; a.ld = ld; a.K = K; a.offsets = d_offsets + img0; a.resp = resp_abs;
