@@ -271,9 +271,11 @@ struct PostMArgs {
 
 // 8 waves: wave = (wm, wn), wm = wave >> 2 owns descriptors [64 wm, +64), wn = wave & 3 owns clusters [64 wn, +64)
 __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostMArgs a) {
-  __shared__ double la[PM_ROWS * F64_KCP];
-  __shared__ double lb[PM_COLS * F64_KCP];
-  __shared__ double red[PM_ROWS][4];
+  // double-buffered operand chunks: the global loads of chunk c+1 are in flight while chunk c runs on the MFMA pipe
+  extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+  double* const la0 = reinterpret_cast<double*>(pm_smem);            // [2][PM_ROWS * F64_KCP]
+  double* const lb0 = la0 + 2 * PM_ROWS * F64_KCP;                   // [2][PM_COLS * F64_KCP]
+  double (*red)[4] = reinterpret_cast<double (*)[4]>(lb0 + 2 * PM_COLS * F64_KCP);   // [PM_ROWS][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int64_t r0 = (int64_t)blockIdx.x * PM_ROWS;
@@ -284,23 +286,43 @@ __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostM
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f64x4_t{0.0, 0.0, 0.0, 0.0};
 
+  // thread t stages inner index jj = t & 15 of rows (t >> 4) + 32 q: A rows q < 4 (descriptors), B rows q < 8 (clusters)
+  const int jj = tid & 15, rr = tid >> 4;
+  float xa[PM_ROWS / 32];
+  double tb[PM_COLS / 32];
+  auto fetch = [&](int k0) {
+    const int j = k0 + jj;
+#pragma unroll
+    for (int q = 0; q < PM_ROWS / 32; ++q) {
+      const int r = rr + 32 * q;
+      xa[q] = (r0 + r < a.total && j < kd) ? a.X[(r0 + r) * a.ld + (j < a.D ? j : j - a.D)] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < PM_COLS / 32; ++q) {
+      const int c = rr + 32 * q;
+      tb[q] = (c < a.K && j < kd) ? a.tab2[(int64_t)c * kd + j] : 0.0;
+    }
+  };
+  auto stash = [&](int k0, int buf) {
+    const bool sq = k0 + jj >= a.D;   // X**2 squared in fp32 first (sklearn _gaussian_mixture.py:500)
+    double* la = la0 + buf * (PM_ROWS * F64_KCP);
+    double* lb = lb0 + buf * (PM_COLS * F64_KCP);
+#pragma unroll
+    for (int q = 0; q < PM_ROWS / 32; ++q) la[(rr + 32 * q) * F64_KCP + jj] = sq ? (double)(xa[q] * xa[q]) : (double)xa[q];
+#pragma unroll
+    for (int q = 0; q < PM_COLS / 32; ++q) lb[(rr + 32 * q) * F64_KCP + jj] = tb[q];
+  };
+  fetch(0);
+  stash(0, 0);
+  __syncthreads();
+  int buf = 0;
   for (int k0 = 0; k0 < kd; k0 += F64_KC) {
+    const bool more = k0 + F64_KC < kd;
+    if (more) fetch(k0 + F64_KC);
+    f64_chunk_mma<4, 4>(la0 + buf * (PM_ROWS * F64_KCP), lb0 + buf * (PM_COLS * F64_KCP), wm * 64, wn * 64, lane, acc);
+    if (more) stash(k0 + F64_KC, buf ^ 1);
     __syncthreads();
-    for (int idx = tid; idx < PM_ROWS * F64_KC; idx += PM_THREADS) {   // consecutive threads -> consecutive inner index
-      const int r = idx >> 4, j = k0 + (idx & 15);
-      double v = 0.0;
-      if (r0 + r < a.total && j < kd) {
-        const float x = a.X[(r0 + r) * a.ld + (j < a.D ? j : j - a.D)];
-        v = j < a.D ? (double)x : (double)(x * x);   // X**2 squared in fp32 first (sklearn _gaussian_mixture.py:500)
-      }
-      la[r * F64_KCP + (idx & 15)] = v;
-    }
-    for (int idx = tid; idx < PM_COLS * F64_KC; idx += PM_THREADS) {
-      const int c = idx >> 4, j = k0 + (idx & 15);
-      lb[c * F64_KCP + (idx & 15)] = (c < a.K && j < kd) ? a.tab2[(int64_t)c * kd + j] : 0.0;
-    }
-    __syncthreads();
-    f64_chunk_mma<4, 4>(la, lb, wm * 64, wn * 64, lane, acc);
+    buf ^= 1;
   }
 
   // ---- softmax over clusters (scipy logsumexp: max, log-sum-exp, subtract, exp).  This lane holds, for column
@@ -335,13 +357,18 @@ __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostM
       mx[mi][r] = fmax(fmax(red[row][0], red[row][1]), fmax(red[row][2], red[row][3]));
     }
   __syncthreads();
+  // e = exp(logp - max) is formed once and kept in the accumulators; gamma = e / sum (within 2 ulp of scipy's
+  // exp(logp - logsumexp)); the row's log-sum-exp itself is only needed by training
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       double s = 0.0;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) s += exp(acc[mi][ni][r] - mx[mi][r]);
+      for (int ni = 0; ni < 4; ++ni) {
+        acc[mi][ni][r] = exp(acc[mi][ni][r] - mx[mi][r]);
+        s += acc[mi][ni][r];
+      }
       for (int q = 8; q >= 1; q >>= 1) s += __shfl_xor(s, q, 64);
       if (col == 0) red[wm * 64 + 16 * mi + 4 * r + rq][wn] = s;
     }
@@ -351,14 +378,15 @@ __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostM
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wm * 64 + 16 * mi + 4 * r + rq;
-      const double lse = mx[mi][r] + log(((red[row][0] + red[row][1]) + red[row][2]) + red[row][3]);
+      const double sum = ((red[row][0] + red[row][1]) + red[row][2]) + red[row][3];
+      const double rs = 1.0 / sum;
       if (r0 + row < a.total) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           const int k = wn * 64 + 16 * ni + col;
-          if (k < a.K) a.resp[(r0 + row) * a.K + k] = exp(acc[mi][ni][r] - lse);
+          if (k < a.K) a.resp[(r0 + row) * a.K + k] = acc[mi][ni][r] * rs;
         }
-        if (a.lse != nullptr && wn == 0 && col == 0) a.lse[r0 + row] = lse;
+        if (a.lse != nullptr && wn == 0 && col == 0) a.lse[r0 + row] = mx[mi][r] + log(sum);
       }
     }
 }
@@ -428,10 +456,12 @@ __device__ __forceinline__ double nterm_t(double v, double p) {
 // RAW = leave the sums as they are (one EM M-step's sufficient statistics per descriptor chunk) instead of the Fisher epilogue
 template <bool RAW, int PM = 2, int NM = 0, bool OUT64 = true>
 __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomMArgs a) {
-  __shared__ double la[256 * F64_KCP];   // gamma^T chunk: [k][i]
-  __shared__ double lb[128 * F64_KCP];   // Z chunk:       [c][i], c = 64 wn + (x: 0..31 | x**2: 32..63)
-  __shared__ double s0s[256];
-  __shared__ double red[8];
+  // double-buffered chunks (global loads of chunk c+1 in flight during the MFMAs of chunk c)
+  extern __shared__ __attribute__((aligned(16))) char mm_smem[];
+  double* const la0 = reinterpret_cast<double*>(mm_smem);   // [2][256 * F64_KCP]  gamma^T chunk: [k][i]
+  double* const lb0 = la0 + 2 * 256 * F64_KCP;              // [2][128 * F64_KCP]  Z chunk: [c][i], c = 64 wn + (x: 0..31 | x**2: 32..63)
+  double* const s0s = lb0 + 2 * 128 * F64_KCP;              // [256]
+  double* const red = s0s + 256;                            // [8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int img = blockIdx.y, dblk = blockIdx.x * MM_DIMS, d0 = dblk + 32 * wn;
@@ -446,30 +476,54 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f64x4_t{0.0, 0.0, 0.0, 0.0};
   double s0 = 0.0;
 
+  // staging: gamma: thread t takes cluster k = t & 255 of descriptors (t >> 8) + 2 q, q < 8 (consecutive threads ->
+  // consecutive clusters); Z: dim dd = t & 63 of descriptors (t >> 6) + 8 q, q < 2
+  const int gk = tid & 255, gi = tid >> 8, zd = tid & 63, zi = tid >> 6;
+  const int zc = 64 * (zd >> 5) + (zd & 31);
+  double gv[8];
+  float zv[2];
+  auto fetch = [&](int i0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int ii = gi + 2 * q;
+      gv[q] = (i0 + ii < n && gk < K) ? a.resp[(row0 + i0 + ii) * K + gk] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ii = zi + 8 * q;
+      zv[q] = (i0 + ii < n && dblk + zd < D) ? a.X[(row0 + i0 + ii) * a.ld + dblk + zd] : 0.f;
+    }
+  };
+  auto stash = [&](int buf) {
+    double* la = la0 + buf * (256 * F64_KCP);
+    double* lb = lb0 + buf * (128 * F64_KCP);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) la[gk * F64_KCP + gi + 2 * q] = gv[q];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ii = zi + 8 * q;
+      lb[zc * F64_KCP + ii] = (double)zv[q];
+      lb[(zc + 32) * F64_KCP + ii] = (double)(zv[q] * zv[q]);   // np.power(descriptors, 2) in fp32 (fisher_vector.py:104)
+    }
+  };
+  if (n > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  int buf = 0;
   for (int i0 = 0; i0 < n; i0 += F64_KC) {
-    __syncthreads();
-    for (int idx = tid; idx < 256 * F64_KC; idx += MM_THREADS) {  // consecutive threads -> consecutive clusters
-      const int ii = idx >> 8, k = idx & 255;
-      la[k * F64_KCP + ii] = (i0 + ii < n && k < K) ? a.resp[(row0 + i0 + ii) * K + k] : 0.0;
-    }
-    for (int idx = tid; idx < MM_DIMS * F64_KC; idx += MM_THREADS) {  // consecutive threads -> consecutive dims
-      const int ii = idx >> 6, dd = idx & 63, d = dblk + dd;
-      double v = 0.0, v2 = 0.0;
-      if (i0 + ii < n && d < D) {
-        const float x = a.X[(row0 + i0 + ii) * a.ld + d];
-        v = (double)x;
-        v2 = (double)(x * x);                                  // np.power(descriptors, 2) in fp32 (fisher_vector.py:104)
-      }
-      const int c = 64 * (dd >> 5) + (dd & 31);
-      lb[c * F64_KCP + ii] = v;
-      lb[(c + 32) * F64_KCP + ii] = v2;
-    }
-    __syncthreads();
+    const bool more = i0 + F64_KC < n;
+    if (more) fetch(i0 + F64_KC);
+    const double* la = la0 + buf * (256 * F64_KCP);
     if (tid < 256) {
 #pragma unroll
-      for (int ii = 0; ii < F64_KC; ++ii) s0 += la[tid * F64_KCP + ii];   // zeros past n
+      for (int ii = 0; ii < F64_KC; ++ii) s0 += la[tid * F64_KCP + ii];   // zeros past n; descriptor order
     }
-    f64_chunk_mma<4, 4>(la, lb, wm * 64, wn * 64, lane, acc);
+    f64_chunk_mma<4, 4>(la, lb0 + buf * (128 * F64_KCP), wm * 64, wn * 64, lane, acc);
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
   if (tid < 256) s0s[tid] = s0;
   __syncthreads();
@@ -549,6 +603,19 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
     for (int wv = 1; wv < 8; ++wv) t = is_max ? fmax(t, red[wv]) : t + red[wv];
     a.partial[(int64_t)img * a.dblocks + blockIdx.x] = t;
   }
+}
+
+constexpr size_t MM_LDS = (size_t)(2 * 256 * F64_KCP + 2 * 128 * F64_KCP + 256 + 8) * sizeof(double);
+template <bool RAW, int PM, int NM, bool OUT64>
+static int launch_moments(pvs_ctx* ctx, dim3 grid, const MomMArgs& m) {
+  auto k = fisher_moments_mfma_kernel<RAW, PM, NM, OUT64>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MM_LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(MM_THREADS), MM_LDS, ctx->stream, m);
+  return PVS_OK;
 }
 
 // ------------------------------------------------------------------------------------ K5 moments + gradients
@@ -752,8 +819,14 @@ static int posterior_mfma_on(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int
   hipLaunchKernelGGL(build_tab2_kernel, dim3((unsigned)((kd + 255) / 256)), dim3(256), 0, ctx->stream, g->d_prec, g->d_mup,
                      g->K, g->D, tab2);
   PostMArgs a{x, total, g->D, ld, g->K, tab2, g->d_const, d_resp, d_lse};
+  constexpr size_t lds = (size_t)(2 * PM_ROWS * F64_KCP + 2 * PM_COLS * F64_KCP + PM_ROWS * 4) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_posterior_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
   ScopedTimer tm(ctx, T_FPOST);
-  hipLaunchKernelGGL(gmm_posterior_mfma_kernel, dim3((unsigned)((total + PM_ROWS - 1) / PM_ROWS)), dim3(PM_THREADS), 0, ctx->stream, a);
+  hipLaunchKernelGGL(gmm_posterior_mfma_kernel, dim3((unsigned)((total + PM_ROWS - 1) / PM_ROWS)), dim3(PM_THREADS), lds, ctx->stream, a);
   PVS_HIP(hipGetLastError());
   return PVS_OK;
 }
@@ -799,11 +872,11 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
                out_b, out_f64, partial, dblocks, nullptr, nullptr};
     const int pm = prm.power_norm_weight == 1.0 ? 0 : (prm.power_norm_weight == 0.5 ? 1 : 2);
     const int nm = norm_mode == 2 ? 2 : (norm_mode == 0 ? 0 : 1);
-    const dim3 grid((unsigned)dblocks, (unsigned)n_img), blk(MM_THREADS);
-#define PVS_MOM(PMV, NMV)                                                                                             \
-  do {                                                                                                                \
-    if (out_f64) hipLaunchKernelGGL((fisher_moments_mfma_kernel<false, PMV, NMV, true>), grid, blk, 0, ctx->stream, m); \
-    else hipLaunchKernelGGL((fisher_moments_mfma_kernel<false, PMV, NMV, false>), grid, blk, 0, ctx->stream, m);        \
+    const dim3 grid((unsigned)dblocks, (unsigned)n_img);
+#define PVS_MOM(PMV, NMV)                                                                             \
+  do {                                                                                                \
+    if (out_f64) PVS_TRY((launch_moments<false, PMV, NMV, true>(ctx, grid, m)));                      \
+    else PVS_TRY((launch_moments<false, PMV, NMV, false>(ctx, grid, m)));                             \
   } while (0)
     if (pm == 1 && nm == 2) PVS_MOM(1, 2);        // the reference's defaults: p = 0.5, L2
     else if (pm == 0 && nm == 2) PVS_MOM(0, 2);
@@ -897,7 +970,7 @@ int launch_gmm_em_step(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, i
       ScopedTimer tm(ctx, T_FMOM);
       MomMArgs m{x, D, ld, K, off, resp - t0 * K, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, 1.0, 2, 2.0,
                  nullptr, 1, nullptr, dblocks, raw, raw0};
-      hipLaunchKernelGGL(fisher_moments_mfma_kernel<true>, dim3((unsigned)dblocks, (unsigned)nch), dim3(MM_THREADS), 0, ctx->stream, m);
+      PVS_TRY((launch_moments<true, 2, 0, true>(ctx, dim3((unsigned)dblocks, (unsigned)nch), m)));
     }
     hipLaunchKernelGGL(em_reduce_chunks_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, raw0, nch, (int64_t)K, d_stats, first);
     hipLaunchKernelGGL(em_reduce_chunks_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, raw, nch, len, d_stats + K, first);
