@@ -162,6 +162,15 @@ int pvs_cosine_topk_f16_dev(pvs_ctx* ctx, const void* d_Q16, int64_t nq, const v
                             int64_t* d_idx, float* d_val);
 int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L, int k,
                     int64_t* out_idx, float* out_val);
+/* The same lists as pvs_cosine_topk_dev(col_offset 0, merge 0) -- bit-identical indices AND scores -- computed faster:
+ * all pairs are scored with fp16 operands under a proven error bound, the columns within twice that bound of each query's
+ * approximate k-th best are re-scored with the exact fp32 recurrence of the f32 GEMM kernel, and those are ranked.
+ * Inputs that do not qualify (k > 128, N > 32768, rows not 16-B aligned or L % 8 != 0, non-finite values) silently take
+ * the plain exact path.  h_stats (optional, int64[4]): [0] 1 if the filter ran, [1] queries redone by the exact path
+ * (more candidates than slots), [2] candidates re-scored, [3] candidate slots per query. */
+int pvs_cosine_topk_filtered_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L,
+                                 const float* d_inv_q, const float* d_inv_db, int k, int64_t* d_idx, float* d_val,
+                                 int64_t* h_stats);
 /* merges per-rank top-k lists (multi-GPU: each rank scored its own DB shard): lists [n_lists][nq][k]. */
 int pvs_topk_merge_dev(pvs_ctx* ctx, const int64_t* d_idx_lists, const float* d_val_lists, int n_lists,
                        int64_t nq, int k, int64_t* d_idx, float* d_val);
@@ -197,7 +206,7 @@ int pvs_min_update_dev(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py) */
 /* Enable per-kernel-family HIP-event timing on the context's stream. which: 0 assign, 1 aggregate,
- * 2 cosine gemm, 3 top-k, 4 fisher posterior, 5 fisher moments, 6 norms/misc. */
+ * 2 cosine gemm, 3 top-k, 4 fisher posterior, 5 fisher moments, 6 norms/misc, 7 exact re-scoring (filtered top-k). */
 #define PVS_TIMER_SLOTS 8
 int pvs_timers_enable(pvs_ctx* ctx, int on);
 int pvs_timers_reset(pvs_ctx* ctx);

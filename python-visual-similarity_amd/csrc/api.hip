@@ -655,6 +655,25 @@ PVS_EXPORT int pvs_cosine_topk_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, c
   return cosine_topk_impl(ctx, d_Q, nq, d_DB, N, L, false, d_inv_q, d_inv_db, k, col_offset, merge, d_idx, d_val);
 }
 
+// Exact top-k through the fp16 prefilter + exact re-scoring (filter.hip); inputs that do not qualify take the plain path.
+PVS_EXPORT int pvs_cosine_topk_filtered_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L,
+                                            const float* d_inv_q, const float* d_inv_db, int k, int64_t* d_idx, float* d_val,
+                                            int64_t* h_stats) {
+  PVS_NEED(ctx, "ctx");
+  if (h_stats) h_stats[0] = h_stats[1] = h_stats[2] = h_stats[3] = 0;
+  if (nq <= 0) return PVS_OK;
+  PVS_NEED(d_Q, "Q");
+  PVS_NEED(d_idx, "idx");
+  PVS_NEED(d_val, "val");
+  PVS_HIP(hipSetDevice(ctx->device));
+  if (N > 0 && d_DB != nullptr) {
+    const int rc = launch_cosine_topk_filtered(ctx, d_Q, nq, d_DB, N, L, d_inv_q, d_inv_db, k, 0, d_idx, d_val, h_stats);
+    if (rc != PVS_ERR_UNSUPPORTED) return rc;
+    if (h_stats) h_stats[0] = h_stats[1] = h_stats[2] = h_stats[3] = 0;
+  }
+  return cosine_topk_impl(ctx, d_Q, nq, d_DB, N, L, false, d_inv_q, d_inv_db, k, 0, 0, d_idx, d_val);
+}
+
 PVS_EXPORT int pvs_cosine_topk_f16_dev(pvs_ctx* ctx, const void* d_Q16, int64_t nq, const void* d_DB16, int64_t N,
                                        int64_t L, const float* d_inv_q, const float* d_inv_db, int k, int64_t col_offset,
                                        int merge, int64_t* d_idx, float* d_val) {

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <vector>
+#include <cstring>
 
 #include "../gemm_mfma.hpp"
 
@@ -163,6 +164,46 @@ static void run(const char* name, const void* A, const float* inv, int64_t N, in
   CK(hipFree(d_t)); if (part) CK(hipFree(part));
 }
 
+// Which scalar recurrence reproduces the f32 MFMA accumulation bit for bit?  (needed by an exact re-scoring kernel)
+static void chain_check(const float* A, const float* inv, const float* out, int64_t N, int64_t L, const int* sm, const int* sn, int ns) {
+  std::vector<float> ra(L), rb(L);
+  int match[6] = {0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < ns; ++s) {
+    const int i = sm[s], j = sn[s];
+    float si, sj, got;
+    CK(hipMemcpy(ra.data(), A + (int64_t)i * g_ld, L * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(rb.data(), A + (int64_t)j * g_ld, L * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&si, inv + i, 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&sj, inv + j, 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&got, out + (int64_t)i * N + j, 4, hipMemcpyDeviceToHost));
+    float res[6];
+    for (int v = 0; v < 6; ++v) {
+      float tot = 0.f;
+      for (int64_t c0 = 0; c0 < L; c0 += 1024) {
+        float acc = 0.f;
+        for (int64_t b8 = c0; b8 < c0 + 1024 && b8 < L; b8 += 8)
+          for (int e = 0; e < 4; ++e) {
+            const int64_t k1 = b8 + e, k2 = b8 + 4 + e;
+            const float a1 = ra[k1], b1 = rb[k1], a2 = ra[k2], b2 = rb[k2];
+            switch (v) {
+              case 0: acc = fmaf(a1, b1, acc); acc = fmaf(a2, b2, acc); break;          // h = 0 then h = 1, fused
+              case 1: acc = fmaf(a2, b2, acc); acc = fmaf(a1, b1, acc); break;          // h = 1 then h = 0
+              case 2: acc = acc + fmaf(a2, b2, a1 * b1); break;                          // dot2 then add
+              case 3: acc = acc + (a1 * b1); acc = acc + (a2 * b2); break;               // unfused
+              case 4: acc = (float)((double)acc + (double)a1 * b1 + (double)a2 * b2); break;   // exact dot2, one rounding
+              case 5: acc = fmaf(a1, b1, fmaf(a2, b2, 0.f)) + acc; break;
+            }
+          }
+        tot += acc;
+      }
+      res[v] = tot * (si * sj);
+      match[v] += (res[v] == got);
+    }
+    if (s < 4) printf("  sample (%d,%d): device %.9g  v0 %.9g v1 %.9g v2 %.9g v3 %.9g v4 %.9g v5 %.9g\n", i, j, got, res[0], res[1], res[2], res[3], res[4], res[5]);
+  }
+  printf("chain check over %d samples: bitwise matches v0 %d v1 %d v2 %d v3 %d v4 %d v5 %d\n", ns, match[0], match[1], match[2], match[3], match[4], match[5]);
+}
+
 int main(int argc, char** argv) {
   const int64_t N = argc > 1 ? atoll(argv[1]) : 8189, L = argc > 2 ? atoll(argv[2]) : 32768;
   g_ld = L + (argc > 3 ? atoll(argv[3]) : 0);
@@ -187,6 +228,7 @@ int main(int argc, char** argv) {
   const int which = argc > 4 ? atoi(argv[4]) : 0;
   if (which == 0 || which == 1) {
     RUN(128, 128, 2, 2, 2, false, 2, 1);
+    if (argc > 5 && !strcmp(argv[5], "chain")) { RUN(128, 128, 2, 2, 2, false, 2, 1); chain_check(A, inv, out, N, L, sm.data(), sn.data(), ns); return 0; }
     run<128, 128, 2, 2, 2, false, 2, true>("128x128 stamped", A, inv, N, L, out, ns, ref.data(), sm.data(), sn.data(), 1);
     RUN(128, 128, 2, 2, 2, true, 2, 16);
   }

@@ -41,7 +41,7 @@ void set_error(const char* fmt, ...);
 
 constexpr int WAVE = 64;
 
-enum TimerSlot { T_ASSIGN = 0, T_AGGREGATE = 1, T_GEMM = 2, T_TOPK = 3, T_FPOST = 4, T_FMOM = 5, T_MISC = 6 };
+enum TimerSlot { T_ASSIGN = 0, T_AGGREGATE = 1, T_GEMM = 2, T_TOPK = 3, T_FPOST = 4, T_FMOM = 5, T_MISC = 6, T_RESCORE = 7 };
 
 struct TimerRec {
   hipEvent_t a, b;
@@ -58,7 +58,8 @@ struct pvs_ctx {
   // grow-only scratch areas (device)
   // 0 host-API input staging, 1 scratch (labels, tables, responsibilities), 2 host-API outputs / score panel,
   // 3 PCA projections, 4 materialised RootSIFT rows
-  static constexpr int NWS = 5;
+  // 5 fp16 row copies (filtered top-k), 6 filtered top-k lists / candidates
+  static constexpr int NWS = 7;
   void* ws[NWS] = {};
   size_t ws_bytes[NWS] = {};
   // timers
@@ -132,6 +133,13 @@ int launch_cosine_f32_dual(pvs_ctx* ctx, const float* A, int64_t M, const float*
 int launch_cosine_f16(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
                       const float* invb, float* out, int64_t ldo);
 int launch_f32_to_f16(pvs_ctx* ctx, const float* src, int64_t n, void* dst);
+int launch_cosine_f16_bounded(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
+                              const float* invb, float* out, int64_t ldo);
+// exact top-k through an fp16 prefilter + exact re-scoring (filter.hip); returns PVS_ERR_UNSUPPORTED when the inputs
+// do not qualify (the caller then runs the plain exact path)
+int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L,
+                                const float* invq, const float* invdb, int k, int64_t col_offset, int64_t* d_idx, float* d_val,
+                                int64_t* h_stats);
 int launch_cosine_f64(pvs_ctx* ctx, const double* A, int64_t M, const double* B, int64_t N, int64_t L, double* out);
 int launch_topk(pvs_ctx* ctx, const float* scores, int64_t nq, int64_t ncols, int64_t ld, int k,
                 int64_t col_offset, int merge, int64_t* d_idx, float* d_val);

@@ -57,6 +57,12 @@ int launch_row_inv_norms(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L
 // workgroups would be mostly empty -- hands the remaining tiles to a deterministic split-K tail.
 using GemmMain = GemmCfg<128, 128, 2, 2, 2, false>;   // exact fp32: 2 workgroups per CU
 using GemmHalf = GemmCfg<256, 256, 2, 4, 2, true>;    // fp16 operands: 1 workgroup (8 waves) per CU
+using GemmPre = GemmCfg<128, 128, 2, 2, 2, true>;     // fp16 operands, chains of 1024 k summed in fp32 (bounded error: prefilter)
+// MODEL: 0 exact fp32, 1 fp16 256x256 single-level, 2 fp16 128x128 two-level
+template <int MODEL> struct GemmModel;
+template <> struct GemmModel<0> { using Cfg = GemmMain; static constexpr bool F16 = false, TWO = true; static constexpr int BM = 128, WN = 2, PER_CU = 2; };
+template <> struct GemmModel<1> { using Cfg = GemmHalf; static constexpr bool F16 = true, TWO = false; static constexpr int BM = 256, WN = 4, PER_CU = 1; };
+template <> struct GemmModel<2> { using Cfg = GemmPre; static constexpr bool F16 = true, TWO = true; static constexpr int BM = 128, WN = 2, PER_CU = 2; };
 
 struct GemmPlanKey {
   int tiles_m = -1, tiles_n = -1, symm = -1, slots = -1;
@@ -70,7 +76,7 @@ struct GemmPlan {
   GemmTile* d_tiles = nullptr;
   size_t cap = 0;
 };
-static GemmPlan g_plan[2];  // [0] fp32 kernel, [1] fp16 kernel: one cached plan each per process
+static GemmPlan g_plan[3];  // one cached plan per GEMM model (see GemmModel) per process
 
 static int build_plan(pvs_ctx* ctx, int which, int tiles_m, int tiles_n, bool symm, int slots, GemmPlan** out) {
   GemmPlan& P = g_plan[which];
@@ -120,13 +126,15 @@ static int build_plan(pvs_ctx* ctx, int which, int tiles_m, int tiles_n, bool sy
   return PVS_OK;
 }
 
-template <bool SYMM, bool F16, bool DUAL = false>
+template <bool SYMM, int MODEL, bool DUAL = false>
 static int launch_gemm_mfma(pvs_ctx* ctx, GemmArgs g, const GemmPlan& plan) {
-  using Cfg = std::conditional_t<F16, GemmHalf, GemmMain>;
-  constexpr int BM = F16 ? 256 : 128, WM = 2, WN = F16 ? 4 : 2;
-  // fp16: single-level accumulation (input rounding dominates); LDS-DMA interleaved into the MFMA phase pays only
-  // in the general (non-symmetric) order (measured 3.62 vs 3.91 ms; symmetric 2.19 vs 1.98 ms)
-  constexpr bool TWO = !F16, ILV = F16 && !SYMM;
+  using GM = GemmModel<MODEL>;
+  using Cfg = typename GM::Cfg;
+  constexpr bool F16 = GM::F16;
+  constexpr int BM = GM::BM, WM = 2, WN = GM::WN;
+  // fp16 256x256: single-level accumulation (input rounding dominates); LDS-DMA interleaved into the MFMA phase pays
+  // only in the general (non-symmetric) order (measured 3.62 vs 3.91 ms; symmetric 2.19 vs 1.98 ms)
+  constexpr bool TWO = GM::TWO, ILV = MODEL == 1 && !SYMM;
   auto kfull = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_FULL, false, F16, TWO, ILV, DUAL>;
   auto kpart = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_PARTIAL, false, F16, TWO, ILV, DUAL>;
   auto kred = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_REDUCE, false, F16, TWO, ILV, DUAL>;
@@ -167,25 +175,25 @@ static int launch_gemm_mfma(pvs_ctx* ctx, GemmArgs g, const GemmPlan& plan) {
 }
 
 // shared front end of the two MFMA paths
-template <bool F16>
+template <int MODEL>
 static int cosine_mfma(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
                        const float* invb, float* out, int64_t ldo, float* out_t = nullptr, int64_t ldt = 0) {
-  constexpr int BT = F16 ? 256 : 128;
+  constexpr int BT = GemmModel<MODEL>::BM;
   const int tiles_m = (int)((M + BT - 1) / BT), tiles_n = (int)((N + BT - 1) / BT);
   if ((int64_t)tiles_m * tiles_n > 0x3fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "cosine: too many tiles for one launch");
   // self-similarity: same operand, same norms -> only the upper triangle is computed, the rest mirrored
   const bool symm = (A == B) && (M == N) && (inva == invb) && out_t == nullptr;
   GemmPlan* plan = nullptr;
-  PVS_TRY(build_plan(ctx, F16 ? 1 : 0, tiles_m, tiles_n, symm, ctx->num_cu * (F16 ? 1 : 2), &plan));
+  PVS_TRY(build_plan(ctx, MODEL, tiles_m, tiles_n, symm, ctx->num_cu * GemmModel<MODEL>::PER_CU, &plan));
   GemmArgs g{};
   g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = L; g.ldb = L; g.inva = inva; g.invb = invb;
   g.out = out; g.ldo = ldo; g.out_t = out_t; g.ldt = ldt; g.tiles = plan->d_tiles; g.splitk = 1;
   PVS_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(const_cast<float**>(&g.zero16)), HIP_SYMBOL(g_zero16)));
-  if (symm) return launch_gemm_mfma<true, F16>(ctx, g, *plan);
-  if constexpr (!F16) {
-    if (out_t) return launch_gemm_mfma<false, false, true>(ctx, g, *plan);
+  if (symm) return launch_gemm_mfma<true, MODEL>(ctx, g, *plan);
+  if constexpr (MODEL == 0) {
+    if (out_t) return launch_gemm_mfma<false, 0, true>(ctx, g, *plan);
   }
-  return launch_gemm_mfma<false, F16>(ctx, g, *plan);
+  return launch_gemm_mfma<false, MODEL>(ctx, g, *plan);
 }
 
 // ------------------------------------------------------------------------------------- fp32 -> fp16 encodings
@@ -226,7 +234,17 @@ int launch_cosine_f16(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int
     PVS_FAIL(PVS_ERR_UNSUPPORTED, "fp16 cosine needs 16-B aligned rows (L %% 8 == 0), got L = %lld", (long long)L);
   if (L > (int64_t)16 * 1024 * 1024) PVS_FAIL(PVS_ERR_UNSUPPORTED, "fp16 cosine: L too large");
   ScopedTimer tm(ctx, T_GEMM);
-  return cosine_mfma<true>(ctx, A, M, B, N, L, inva, invb, out, ldo);
+  return cosine_mfma<1>(ctx, A, M, B, N, L, inva, invb, out, ldo);
+}
+
+// fp16 operands with the accumulation error bounded by chains of 1024 k (the prefilter of the exact filtered top-k)
+int launch_cosine_f16_bounded(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
+                              const float* invb, float* out, int64_t ldo) {
+  if (M <= 0 || N <= 0) return PVS_OK;
+  if (L <= 0 || L % 8 != 0 || reinterpret_cast<uintptr_t>(A) % 16 || reinterpret_cast<uintptr_t>(B) % 16)
+    PVS_FAIL(PVS_ERR_UNSUPPORTED, "fp16 cosine needs 16-B aligned rows (L %% 8 == 0), got L = %lld", (long long)L);
+  ScopedTimer tm(ctx, T_GEMM);
+  return cosine_mfma<2>(ctx, A, M, B, N, L, inva, invb, out, ldo);
 }
 
 // ------------------------------------------------------------------------------------- generic tiled fallback
@@ -293,7 +311,7 @@ int launch_cosine_f32(pvs_ctx* ctx, const float* A, int64_t M, const float* B, i
                     (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (L <= (int64_t)8 * 1024 * 1024);
   ScopedTimer tm(ctx, T_GEMM);
   if (fast) {
-    PVS_TRY(cosine_mfma<false>(ctx, A, M, B, N, L, inva, invb, out, ldo));
+    PVS_TRY(cosine_mfma<0>(ctx, A, M, B, N, L, inva, invb, out, ldo));
   } else {
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
     hipLaunchKernelGGL(cosine_gemm_generic_kernel<float>, grid, dim3(256), 0, ctx->stream, A, M, B, N, L, inva, invb,
@@ -310,7 +328,7 @@ int launch_cosine_f32_dual(pvs_ctx* ctx, const float* A, int64_t M, const float*
         (L <= (int64_t)8 * 1024 * 1024)))
     PVS_FAIL(PVS_ERR_UNSUPPORTED, "dual-output cosine needs 16-B aligned rows (L %% 4 == 0)");
   ScopedTimer tm(ctx, T_GEMM);
-  return cosine_mfma<false>(ctx, A, M, B, N, L, inva, invb, out, ldo, out_t, ldt);
+  return cosine_mfma<0>(ctx, A, M, B, N, L, inva, invb, out, ldo, out_t, ldt);
 }
 
 int launch_cosine_f64(pvs_ctx* ctx, const double* A, int64_t M, const double* B, int64_t N, int64_t L, double* out) {

@@ -20,7 +20,7 @@ _EXC = {PVS_ERR_INVALID: ValueError, PVS_ERR_NO_DEVICE: RuntimeError, PVS_ERR_OO
         PVS_ERR_UNSUPPORTED: NotImplementedError, PVS_ERR_DIM: RuntimeError}
 
 DESC_F32, DESC_F32_ROOTSIFT, DESC_U8_ROOTSIFT = 0, 1, 2
-TIMER_NAMES = ("assign", "aggregate", "cosine_gemm", "topk", "fisher_posterior", "fisher_moments", "misc")
+TIMER_NAMES = ("assign", "aggregate", "cosine_gemm", "topk", "fisher_posterior", "fisher_moments", "misc", "rescore")
 
 
 class NormParams(C.Structure):
@@ -65,6 +65,7 @@ SIGNATURES = {
     "pvs_cosine_dual_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64],
     "pvs_topk_dev": [_vp, _vp, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp],
     "pvs_cosine_topk_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _i64, _int, _vp, _vp],
+    "pvs_cosine_topk_filtered_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp],
     "pvs_f32_to_f16_dev": [_vp, _vp, _i64, _vp],
     "pvs_cosine_f16_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64],
     "pvs_cosine_topk_f16_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _i64, _int, _vp, _vp],

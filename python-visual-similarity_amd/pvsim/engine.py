@@ -297,6 +297,14 @@ class Context:
         check(_ffi.lib().pvs_cosine_topk_dev(self.handle, ptr(d_q), nq, ptr(d_db), N, L, ptr(d_invq), ptr(d_invdb), k,
                                              col_offset, int(merge), ptr(d_idx), ptr(d_val)))
 
+    def cosine_topk_filtered_dev(self, d_q, nq, d_db, N, L, d_invq, d_invdb, k, d_idx, d_val):
+        """Same lists as cosine_topk_dev (bit-identical), via the fp16 prefilter + exact re-scoring.
+        -> dict(filtered, redone_exact, candidates, slots)"""
+        st = (C.c_int64 * 4)()
+        check(_ffi.lib().pvs_cosine_topk_filtered_dev(self.handle, ptr(d_q), nq, ptr(d_db), N, L, ptr(d_invq), ptr(d_invdb), k,
+                                                      ptr(d_idx), ptr(d_val), st))
+        return {"filtered": bool(st[0]), "redone_exact": int(st[1]), "candidates": int(st[2]), "slots": int(st[3])}
+
     def f32_to_f16_dev(self, d_src, n, d_dst):
         check(_ffi.lib().pvs_f32_to_f16_dev(self.handle, ptr(d_src), n, ptr(d_dst)))
 

@@ -620,3 +620,79 @@ def test_learn_through_the_encoder_api(tables):
     want = orc.fisher_encode([fx(im) for im in images[:2]], fe.clustering_model.weights_, fe.clustering_model.means_,
                              fe.clustering_model.covariances_)
     np.testing.assert_allclose(f, want, rtol=0, atol=FISHER_ATOL)
+
+
+# ======================================================================================= filtered (prefilter + exact re-score) top-k
+def _topk_both(ctx, q, db, k, same):
+    import torch
+    dev = torch.device("cuda", 0)
+    tq = torch.from_numpy(q).to(dev)
+    tdb = tq if same else torch.from_numpy(db).to(dev)
+    nq, L = tq.shape
+    N = tdb.shape[0]
+    iq = torch.empty((nq,), dtype=torch.float32, device=dev)
+    idb = iq if same else torch.empty((N,), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.row_inv_norms_dev(tq.data_ptr(), nq, L, iq.data_ptr())
+    if not same:
+        ctx.row_inv_norms_dev(tdb.data_ptr(), N, L, idb.data_ptr())
+    out = []
+    for filt in (False, True):
+        idx = torch.full((nq, k), -7, dtype=torch.int64, device=dev)
+        val = torch.full((nq, k), -7.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        if filt:
+            st = ctx.cosine_topk_filtered_dev(tq.data_ptr(), nq, tdb.data_ptr(), N, L, iq.data_ptr(), idb.data_ptr(), k,
+                                              idx.data_ptr(), val.data_ptr())
+        else:
+            st = None
+            ctx.cosine_topk_dev(tq.data_ptr(), nq, tdb.data_ptr(), N, L, iq.data_ptr(), idb.data_ptr(), k, 0, False,
+                                idx.data_ptr(), val.data_ptr())
+        ctx.sync()
+        out.append((idx.cpu().numpy(), val.cpu().numpy(), st))
+    return out
+
+
+@pytest.mark.parametrize("case", ["vlad_self_k5", "vlad_self_k100", "queries_vs_db", "partial_chain", "ties_and_near_ties",
+                                  "overflow_to_exact", "not_qualified"])
+def test_filtered_topk_is_bit_identical_to_the_exact_path(gpu_ctx, tables, case):
+    """pvs_cosine_topk_filtered_dev must return exactly what pvs_cosine_topk_dev returns: indices and fp32 score bits."""
+    rng = np.random.default_rng(hash(case) % 2**32)
+    same, k = True, 5
+    if case.startswith("vlad_self"):
+        proto = synth.sift_prototypes()
+        raws = [synth.rootsift(synth.sift_like(int(rng.integers(40, 200)), rng, proto).astype(np.float32)) for _ in range(700)]
+        packed, off = pack_descriptors(raws, 128)
+        q = db = gpu_ctx.vlad_encode(gpu_ctx.codebook(tables["centroids"]), packed, off, DESC_F32)
+        k = 100 if case.endswith("k100") else 5
+    elif case == "queries_vs_db":
+        same = False
+        db = rng.standard_normal((1500, 4096)).astype(np.float32)
+        q = (db[rng.integers(0, 1500, 300)] + 0.7 * rng.standard_normal((300, 4096))).astype(np.float32)
+        k = 10
+    elif case == "partial_chain":            # L = 2600: chains of 1024, 1024 and 552
+        q = db = (rng.standard_normal((900, 2600)) * rng.uniform(1e-3, 1e3, size=(900, 1))).astype(np.float32)
+        k = 7
+    elif case == "ties_and_near_ties":
+        base = rng.standard_normal((300, 2048)).astype(np.float32)
+        dup = base[:100].copy()                                            # exact duplicates: tied scores, index order decides
+        near = (base[100:200] * (1 + 1e-4 * rng.standard_normal((100, 2048)))).astype(np.float32)   # inside the margin
+        q = db = np.concatenate([base, dup, near, np.zeros((3, 2048), np.float32)])                  # and zero rows
+        k = 5
+    elif case == "overflow_to_exact":        # every column within the margin of every other: more candidates than slots
+        c = rng.standard_normal((1, 1024)).astype(np.float32)
+        q = db = (c + 1e-3 * rng.standard_normal((600, 1024))).astype(np.float32)
+        k = 5
+    else:                                    # L % 8 != 0: silently the plain exact path
+        q = db = rng.standard_normal((200, 1001)).astype(np.float32)
+        k = 5
+    (ei, ev, _), (fi, fv, st) = _topk_both(gpu_ctx, np.ascontiguousarray(q), np.ascontiguousarray(db), k, same)
+    assert np.array_equal(ei, fi), (case, np.argwhere(ei != fi)[:5])
+    assert np.array_equal(ev.view(np.uint32), fv.view(np.uint32)), (case, np.argwhere(ev != fv)[:5])
+    if case == "not_qualified":
+        assert not st["filtered"]
+    else:
+        assert st["filtered"] and st["candidates"] >= k * q.shape[0] - 3 * k
+        # the three all-zero rows score 0 against everything (all columns tie): they and the overflow case go to the exact path
+        want_redone = {"overflow_to_exact": q.shape[0], "ties_and_near_ties": 3}.get(case, 0)
+        assert st["redone_exact"] == want_redone, st
