@@ -61,6 +61,10 @@ def parse():
                          "headline): fisher = BASELINE configs[2] (Fisher D=512 K=256 n=196), vlad512 = the per-GPU share of "
                          "configs[3] (n=512 descriptors per image, encode only), fp16sim = configs[4] scaled to one GPU "
                          "(N x N cosine on fp16 encodings + top-10)")
+    ap.add_argument("--retrieval", choices=["exact", "filtered"], default="exact",
+                    help="exact = f32 MFMA GEMM over all pairs (the headline). filtered = the same top-k lists, bit for bit, "
+                         "through the fp16 prefilter + exact re-scoring (pvs_cosine_topk_filtered_dev); single GPU only. The "
+                         "default run also times the filtered variant and reports it under 'filtered_retrieval'.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time one step with host-resident inputs (H2D included)")
     return ap.parse_args()
@@ -347,7 +351,10 @@ def main():
             dist.all_gather_into_tensor(enc_all, enc_loc)
             dist.all_gather_into_tensor(inv_all, inv_loc)
             torch.cuda.current_stream().synchronize()
-        if world == 1:
+        if world == 1 and filtered[0]:
+            filt_stats[0] = ctx.cosine_topk_filtered_dev(enc_loc.data_ptr(), n_loc, enc_loc.data_ptr(), n_loc, L, inv_loc.data_ptr(),
+                                                         inv_loc.data_ptr(), TOPK, idx.data_ptr(), val.data_ptr())
+        elif world == 1:
             pd.retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, N, rank, world, TOPK, score_block, idx, val)
         else:
             # every block pair is scored once (dual-store GEMM), k-candidate lists exchanged, merged
@@ -360,18 +367,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.timers_enable(True)
-    ctx.timers_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    timers = ctx.timers()
-    ctx.timers_enable(False)
+    def timed_steps():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        ctx.timers_enable(True)
+        ctx.timers_reset()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_ = time.perf_counter() - t0_
+        tm_ = ctx.timers()
+        ctx.timers_enable(False)
+        return dt_, tm_
+
+    filtered = [args.retrieval == "filtered" and world == 1]
+    filt_stats = [None]
+    other = None
+    if world == 1:
+        # the variant that is NOT the headline of this run is timed first, its lists kept for the bit-for-bit comparison
+        filtered[0] = not filtered[0]
+        o_dt, o_tm = timed_steps()
+        other = {"dt": o_dt, "timers": o_tm, "idx": idx.clone(), "val": val.clone(), "was_filtered": filtered[0], "stats": filt_stats[0]}
+        filtered[0] = not filtered[0]
+    dt, timers = timed_steps()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -405,7 +425,7 @@ def main():
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flop_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
     traffic, traffic_src = pmc_traffic("pvs::gemm_mfma_kernel")
-    if world != 1 or N != 8189:
+    if world != 1 or N != 8189 or filtered[0]:
         traffic, traffic_src = None, None             # the committed counters are for the default 1-GPU workload
     stages = {k: {"ms_total": round(v[0], 3), "launches": int(v[1]),
                   "ms_avg": round(v[0] / v[1], 4) if v[1] else None} for k, v in timers.items() if v[1]}
@@ -421,8 +441,10 @@ def main():
                                f" D=128, VLAD K=256 encode + {N}x{N} cosine + top-{TOPK}",
                    "images": N, "descriptors_rank0": total_desc, "descriptor_rows": args.desc,
                    "K": K_CLUSTERS, "D": DIM, "topk": TOPK, "parallelism": f"image-sharded x{world}"},
-        "roofline": {"kernel": "gemm_mfma_kernel<128,128,f32> (cosine GEMM: main + split-K tail)", "bound": "mfma", "achieved": round(achieved, 2),
-                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+        "roofline": {"kernel": ("gemm_mfma_kernel<128,128,f16, chains of 1024 k> (prefilter GEMM of the filtered retrieval)" if filtered[0] else
+                                "gemm_mfma_kernel<128,128,f32> (cosine GEMM: main + split-K tail)"), "bound": "mfma", "achieved": round(achieved, 2),
+                     "peak": 2500.0 if filtered[0] else FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / (2500.0 if filtered[0] else FP32_MFMA_PEAK_TFLOPS), 4),
                      "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flop_per_launch,
                      "algorithmic_flop_per_launch": alg_flop,
                      "algorithmic_equiv_TFLOPs": round(alg_flop / (gemm_avg_ms * 1e-3) / 1e12, 2) if gemm_n else None, "avg_launch_ms": round(gemm_avg_ms, 4)},
@@ -433,6 +455,22 @@ def main():
                    if timers["assign"][0] else None},
         "device": ctx.device_name(),
     }
+
+    if other is not None:
+        same_lists = bool(torch.equal(other["idx"], idx)) and bool(torch.equal(other["val"].view(torch.int32), val.view(torch.int32)))
+        f_dt, f_tm, f_st = (other["dt"], other["timers"], other["stats"]) if other["was_filtered"] else (dt, timers, filt_stats[0])
+        e_dt = dt if other["was_filtered"] else other["dt"]
+        out["retrieval"] = args.retrieval
+        out["filtered_retrieval"] = {
+            "what": "same top-k lists through pvs_cosine_topk_filtered_dev: fp16 MFMA prefilter with a proven error bound + exact "
+                    "fp32 re-scoring of the candidates (bit-identical indices and scores; opt-in, --retrieval filtered)",
+            "ms_per_step": round(f_dt / args.steps * 1e3, 3), "images_per_s": round(N / (f_dt / args.steps), 1),
+            "exact_ms_per_step": round(e_dt / args.steps * 1e3, 3),
+            "lists_bit_identical_to_exact": same_lists,
+            "stages_ms": {k: round(v[0] / args.steps, 4) for k, v in f_tm.items() if v[1]},
+            "candidates_per_query": round(f_st["candidates"] / max(n_loc, 1), 2) if f_st else None,
+            "queries_redone_exact": f_st["redone_exact"] if f_st else None}
+        assert same_lists, "filtered retrieval differs from the exact path"
 
     if args.pcie and world == 1:
         h_desc = desc.cpu().numpy()
