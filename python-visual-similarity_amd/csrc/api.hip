@@ -1,6 +1,7 @@
 // C-ABI of libpvsim_hip.so (declared in include/pvsim.h): context, tables, and the host-pointer /
 // device-pointer entry points that sequence the kernels of vlad.hip, fisher.hip, cosine.hip, topk.hip.
 #include <algorithm>
+#include <cmath>
 #include <limits>
 
 #include "common.hpp"
@@ -201,6 +202,30 @@ PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, 
   int st = upload(ctx, &cb->d_cent, centroids, (size_t)K * D);
   if (st == PVS_OK) st = upload(ctx, &cb->d_cpad, pad.data(), pad.size());
   if (st == PVS_OK) st = upload(ctx, &cb->d_cnorm, cn.data(), cn.size());
+  // fp16 copy for the assignment prefilter (vlad.hip): whole table in LDS, every centre inside the fp16 range
+  float amax = 0.f, cmax2 = 0.f;
+  for (size_t i = 0; i < (size_t)K * D; ++i) amax = std::max(amax, std::fabs(centroids[i]));
+  for (int k = 0; k < K; ++k) cmax2 = std::max(cmax2, cn[k]);
+  if (st == PVS_OK && cb->K_pad <= 256 && D <= 128 && amax > 1e-30f && amax <= 1e30f && std::isfinite(cmax2)) {
+    cb->D_pad16 = (D + 15) / 16 * 16;
+    cb->cmax = std::sqrt(cmax2) * (1.f + 1e-6f);
+    int e = 0;
+    (void)std::frexp(amax, &e);                 // amax = m 2^e, m in [0.5, 1)
+    cb->c16_shift = 13 - e;
+    const float sc = std::ldexp(1.f, cb->c16_shift);
+    const size_t tab = (size_t)cb->K_pad * cb->D_pad16;
+    std::vector<_Float16> h16(2 * tab, (_Float16)0.f);
+    for (int k = 0; k < K; ++k)
+      for (int d = 0; d < D; ++d) {
+        const float v = centroids[(size_t)k * D + d] * sc;        // exact (power of two)
+        const _Float16 hi = (_Float16)v;
+        h16[(size_t)k * cb->D_pad16 + d] = hi;
+        h16[tab + (size_t)k * cb->D_pad16 + d] = (_Float16)(v - (float)hi);   // v - hi is exact in fp32
+      }
+    if (hipMalloc(&cb->d_c16, h16.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
+    else if (hipMemcpyAsync(cb->d_c16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
+    if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;   // h16 goes out of scope
+  }
   if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
   if (st != PVS_OK) {
     pvs_codebook_destroy(ctx, cb);
@@ -216,6 +241,7 @@ PVS_EXPORT int pvs_codebook_destroy(pvs_ctx* ctx, pvs_codebook* cb) {
   if (cb->d_cent) hipFree(cb->d_cent);
   if (cb->d_cpad) hipFree(cb->d_cpad);
   if (cb->d_cnorm) hipFree(cb->d_cnorm);
+  if (cb->d_c16) hipFree(cb->d_c16);
   delete cb;
   return PVS_OK;
 }

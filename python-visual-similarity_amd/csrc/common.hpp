@@ -75,6 +75,11 @@ struct pvs_codebook {
   float* d_cent = nullptr;   // [K][D]     exact user layout (for the aggregate step)
   float* d_cpad = nullptr;   // [K_pad][D_pad] zero padded (MFMA operand)
   float* d_cnorm = nullptr;  // [K_pad]   ||c||^2, +inf on padded clusters
+  // fp16 copy for the assignment prefilter (null when K_pad > 256, D > 128 or a centre leaves the fp16 range)
+  void* d_c16 = nullptr;     // [2][K_pad][D_pad16] _Float16: hi = fl16(c 2^c16_shift), lo = fl16(c 2^c16_shift - hi); zero padded
+  int D_pad16 = 0;           // multiple of 16
+  int c16_shift = 0;         // the largest |c| 2^shift lies in [2^12, 2^13)
+  float cmax = 0.f;          // max_k ||c_k||_2
 };
 
 struct pvs_gmm {

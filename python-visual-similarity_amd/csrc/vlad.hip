@@ -10,6 +10,8 @@
 // descriptor rows streamed HBM -> registers.  K2/K3 is HBM/latency bound: per image a stable counting
 // sort of the labels in LDS, then one lane-group per cluster sums its descriptors IN DESCRIPTOR ORDER
 // (bit-identical to the reference's loop given equal labels; no float atomics, run-to-run reproducible).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "desc_load.hpp"
 
@@ -26,6 +28,10 @@ struct AssignArgs {
   const float* cnorm;  // [K_pad], +inf on padded clusters
   int K_pad, D_pad;
   int32_t* labels;
+  // second pass of the prefiltered assignment: workgroup b labels the descriptors of list b (counts live on the device)
+  const int64_t* rows;              // [gridDim][rows_cap]
+  const unsigned long long* nrows;  // [gridDim]
+  int64_t rows_cap;
 };
 
 constexpr int ASSIGN_THREADS = 512;                 // 8 waves, 2 per SIMD
@@ -52,7 +58,9 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign_kernel(AssignArgs a)
   const int ncb = a.K_pad / CB;
   const int nsc = (a.D_pad + ASSIGN_DCHUNK - 1) / ASSIGN_DCHUNK;
   const bool restage = (ncb * nsc) > 1;
-  const int64_t nblocks = (a.total + ASSIGN_ROWS - 1) / ASSIGN_ROWS;
+  const int64_t n_items = a.rows ? (int64_t)a.nrows[blockIdx.x] : a.total;
+  const int64_t nblocks = (n_items + ASSIGN_ROWS - 1) / ASSIGN_ROWS;
+  const int64_t* const my_rows = a.rows ? a.rows + (int64_t)blockIdx.x * a.rows_cap : nullptr;
 
   auto stage = [&](int cb, int sc) {
     const int cw = min(ASSIGN_DCHUNK, a.D_pad - sc * ASSIGN_DCHUNK);
@@ -71,9 +79,11 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign_kernel(AssignArgs a)
     __syncthreads();
   }
 
-  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const int64_t row = blk * ASSIGN_ROWS + wave * 32 + j;
-    const bool rvalid = row < a.total;
+  // list mode: this workgroup walks its own list; otherwise the grid strides over all descriptors
+  for (int64_t blk = my_rows ? 0 : blockIdx.x; blk < nblocks; blk += my_rows ? 1 : gridDim.x) {
+    const int64_t item = blk * ASSIGN_ROWS + wave * 32 + j;
+    const bool rvalid = item < n_items;
+    const int64_t row = (my_rows && rvalid) ? my_rows[item] : item;
     float best = INFINITY;
     int bidx = 0;
 
@@ -172,6 +182,197 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign_kernel(AssignArgs a)
   }
 }
 
+// ----------------------------------------------------------------------------------------- K1 prefilter (fp16 MFMA)
+// The exact kernel above runs at the f32 MFMA rate (vector-FMA speed).  Most descriptors have a clear nearest centre,
+// so a first pass evaluates  v16 = |c|^2 - 2 x.c  on the f16 MFMA with both operands split into two fp16 halves
+// (x = xh + xl, c = ch + cl after a power-of-two scaling into the fp16 range; products ch.xh + ch.xl + cl.xh, fp32
+// accumulate: 3 MFMAs at 16x the f32 rate) under a proven error bound, and settles every descriptor whose best v16 is
+// more than 2 eps below all others -- there the exact kernel's strict-'<' argmin is the same cluster.  The remaining
+// descriptors (near ties, non-finite values) are listed per workgroup and labelled by the exact kernel itself in a second
+// launch, so the labels are those of the exact kernel for every input.
+//   |dot16 - dot32| <= [ 2 2^-22 (operand split) + 2^-22 (dropped cl.xl) + 400 2^-23 (fp32 accumulation of 384 products)
+//                       + 128 2^-24 (the exact kernel's own accumulation) + 1e-9 (flush below the fp16 normal range) ] |x||c|
+//   eps = 2 |dot16 - dot32| + 2^-22 (|c|^2 + 2 |x||c|)   (the final fma of both kernels)
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+struct Assign16Args {
+  const void* X;
+  int64_t total;
+  int D, ld;
+  const _Float16* C16;  // [2][K_pad][D_pad16]  hi | lo
+  const float* cnorm;   // [K_pad], +inf on padded clusters
+  int K_pad, D_pad16;
+  int c_shift;
+  float cmax;
+  int32_t* labels;
+  int64_t* amb_rows;             // [gridDim][cap]: descriptors left to the exact kernel, one list per workgroup
+  unsigned long long* amb_count; // [gridDim]
+  int64_t cap;
+};
+
+template <int NT, int KIND, bool VEC>
+__global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned int s_count;
+  constexpr int CB = 32 * NT;
+  constexpr int stride = 128 + 8;     // halfs, fixed (D <= 128): compile-time fragment offsets; +16 B per row keeps the 16-B reads conflict-free
+  _Float16* lds_h = reinterpret_cast<_Float16*>(smem);
+  _Float16* lds_l = lds_h + CB * stride;
+  float* lds_n = reinterpret_cast<float*>(lds_l + CB * stride);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int nt = a.D_pad16 >> 4;      // k-steps of 16 dims
+  const int64_t nblocks = (a.total + ASSIGN_ROWS - 1) / ASSIGN_ROWS;
+
+  for (int idx = threadIdx.x; idx < 2 * CB * (a.D_pad16 >> 3); idx += ASSIGN_THREADS) {
+    const int per = a.D_pad16 >> 3;
+    const int r = idx / per, c8 = idx - r * per;      // r < 2 CB: hi rows then lo rows
+    *reinterpret_cast<uint4*>(lds_h + r * stride + 8 * c8) = *reinterpret_cast<const uint4*>(a.C16 + (int64_t)r * a.D_pad16 + 8 * c8);
+  }
+  for (int idx = threadIdx.x; idx < CB; idx += ASSIGN_THREADS) lds_n[idx] = a.cnorm[idx];
+  if (threadIdx.x == 0) s_count = 0u;
+  __syncthreads();
+  const float sqrt_d = sqrtf((float)a.D);
+  int64_t* const my_rows = a.amb_rows + (int64_t)blockIdx.x * a.cap;
+
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int64_t row = blk * ASSIGN_ROWS + wave * 32 + j;
+    const bool rvalid = row < a.total;
+    // ---- this lane's half of the row: dims 16 t + 8 h .. + 7, t < 8
+    float xf[8][8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xf[t][q] = 0.f;
+      if (t < nt && rvalid) {
+        const int d = 16 * t + 8 * h;
+        if constexpr (VEC) {
+          if (d < a.D) {
+            const float4 v = load4<KIND>(a.X, row, a.ld, d);
+            xf[t][0] = v.x; xf[t][1] = v.y; xf[t][2] = v.z; xf[t][3] = v.w;
+          }
+          if (d + 4 < a.D) {
+            const float4 v = load4<KIND>(a.X, row, a.ld, d + 4);
+            xf[t][4] = v.x; xf[t][5] = v.y; xf[t][6] = v.z; xf[t][7] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (d + q < a.D) xf[t][q] = load1<KIND>(a.X, row, a.ld, d + q);
+        }
+      }
+    }
+    if constexpr (DescTraits<KIND>::rootsift) {
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += xf[t][q];
+      s += __shfl_xor(s, 32, 64);   // integer-valued rows: the sum is exact, any order
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xf[t][q] = rootsift_apply(xf[t][q], s);
+    }
+    // ---- row norm, row scale (largest |x| 2^shift in [2^12, 2^13)), hi / lo halves
+    float n2 = 0.f, amax = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        n2 = fmaf(xf[t][q], xf[t][q], n2);
+        amax = fmaxf(amax, fabsf(xf[t][q]));
+      }
+    n2 += __shfl_xor(n2, 32, 64);
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    const float nx = sqrtf(n2) * 1.0001f;
+    int ex = 13;
+    if (amax > 0.f) (void)frexpf(amax, &ex);
+    int x_shift = 13 - ex;
+    bool finite = nx <= 3.0e38f;   // false for NaN too
+    if (x_shift > 40 || x_shift < -40) { finite = false; x_shift = 0; }
+    const float xs = ldexpf(1.f, x_shift);
+    f16x8_t xh[8], xl[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float v = xf[t][q] * xs;
+        const _Float16 hi = (_Float16)v;
+        xh[t][q] = hi;
+        xl[t][q] = (_Float16)(v - (float)hi);
+      }
+    // ---- clusters in groups of G tiles (accumulators of one group live at a time): smallest and second smallest v16
+    constexpr int G = NT < 4 ? NT : 4;
+    const float m2s = -2.f * ldexpf(1.f, -(x_shift + a.c_shift));   // v = cn - 2 acc 2^-(shifts): one fma, the scale is exact
+    float best = INFINITY, second = INFINITY;
+    int bidx = 0;
+#pragma unroll
+    for (int g0 = 0; g0 < NT; g0 += G) {
+      f32x16 acc[G];
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (t < nt) {
+#pragma unroll
+          for (int tile = 0; tile < G; ++tile) {
+            const f16x8_t ch = *reinterpret_cast<const f16x8_t*>(lds_h + (32 * (g0 + tile) + j) * stride + 16 * t + 8 * h);
+            const f16x8_t cl = *reinterpret_cast<const f16x8_t*>(lds_l + (32 * (g0 + tile) + j) * stride + 16 * t + 8 * h);
+            acc[tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, xh[t], acc[tile], 0, 0, 0);
+            acc[tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, xl[t], acc[tile], 0, 0, 0);
+            acc[tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, xh[t], acc[tile], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int tile = 0; tile < G; ++tile)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int r0 = 32 * (g0 + tile) + 8 * g + 4 * h;
+          const float4 cn = *reinterpret_cast<const float4*>(lds_n + r0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = fmaf(m2s, acc[tile][4 * g + e], e == 0 ? cn.x : (e == 1 ? cn.y : (e == 2 ? cn.z : cn.w)));
+            // ascending cluster order: strict '<' keeps the first minimum; NaN never enters
+            if (v < best) { second = best; best = v; bidx = r0 + e; }
+            else if (v < second) second = v;
+          }
+        }
+    }
+    {   // the two half-waves hold interleaved cluster subsets of the same descriptor
+      const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
+      const int oi = __shfl_xor(bidx, 32, 64);
+      const bool take = ob < best || (ob == best && oi < bidx);
+      const float nb = take ? ob : best, loser = take ? best : ob;
+      second = fminf(fminf(second, os), loser);
+      best = nb;
+      if (take) bidx = oi;
+    }
+    const float xc = nx * a.cmax;
+    const float eps = 2.f * (4.8e-7f + 2.4e-7f + 4.8e-5f + 7.7e-6f + 1e-9f) * xc * (1.f + sqrt_d * 1e-9f) + 2.4e-7f * (a.cmax * a.cmax + 2.f * xc);
+    const int within = second <= best + 2.f * eps ? 2 : 1;
+    // settled: exactly one cluster within the margin (the minimum itself) and everything finite
+    const bool settled = within == 1 && finite && fabsf(best) <= 3.0e38f;
+    // the rest goes on this workgroup's list: one LDS atomic per wave (ballot + prefix count)
+    const bool amb = h == 0 && rvalid && !settled;
+    const unsigned long long amask = __ballot(amb);
+    unsigned int base = 0;
+    if (amask != 0ull) {
+      if (lane == 0) base = atomicAdd(&s_count, (unsigned int)__popcll(amask));
+      base = __shfl(base, 0, 64);
+    }
+    if (h == 0 && rvalid) {
+      if (settled) a.labels[row] = bidx;
+      else my_rows[base + __popcll(amask & ((1ull << lane) - 1ull))] = row;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.amb_count[blockIdx.x] = s_count;
+}
+
 template <int NT, int KIND>
 static int launch_assign_nt(pvs_ctx* ctx, const AssignArgs& a, bool vec, size_t lds, int grid) {
   auto kv = assign_kernel<NT, KIND, true>;
@@ -194,6 +395,35 @@ static int launch_assign_kind(pvs_ctx* ctx, const AssignArgs& a, int nt, bool ve
   }
 }
 
+template <int NT, int KIND>
+static int launch_assign16_nt(pvs_ctx* ctx, const Assign16Args& p, bool vec, size_t lds, int grid) {
+  auto kv = assign16_kernel<NT, KIND, true>;
+  auto ks = assign16_kernel<NT, KIND, false>;
+  auto k = vec ? kv : ks;
+  PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(grid), dim3(ASSIGN_THREADS), lds, ctx->stream, p);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+template <int KIND>
+static int launch_assign16_kind(pvs_ctx* ctx, const Assign16Args& p, int nt, bool vec, size_t lds, int grid) {
+  switch (nt) {   // the whole (padded) table is one block of 32 nt clusters
+    case 8: return launch_assign16_nt<8, KIND>(ctx, p, vec, lds, grid);
+    case 4: return launch_assign16_nt<4, KIND>(ctx, p, vec, lds, grid);
+    case 2: return launch_assign16_nt<2, KIND>(ctx, p, vec, lds, grid);
+    case 1: return launch_assign16_nt<1, KIND>(ctx, p, vec, lds, grid);
+    default: PVS_FAIL(PVS_ERR_INVALID, "assignment prefilter: unexpected table padding");
+  }
+}
+static int launch_assign16(pvs_ctx* ctx, const Assign16Args& p, int kind, int nt, bool vec, size_t lds, int grid) {
+  switch (kind) {
+    case PVS_DESC_F32: return launch_assign16_kind<PVS_DESC_F32>(ctx, p, nt, vec, lds, grid);
+    case PVS_DESC_F32_ROOTSIFT: return launch_assign16_kind<PVS_DESC_F32_ROOTSIFT>(ctx, p, nt, vec, lds, grid);
+    case PVS_DESC_U8_ROOTSIFT: return launch_assign16_kind<PVS_DESC_U8_ROOTSIFT>(ctx, p, nt, vec, lds, grid);
+    default: PVS_FAIL(PVS_ERR_INVALID, "unknown descriptor kind %d", kind);
+  }
+}
+
 int assign_tiles_for(int K) {
   const int k32 = (K + 31) / 32 * 32;
   return k32 > 128 ? 8 : (k32 > 64 ? 4 : (k32 > 32 ? 2 : 1));
@@ -207,7 +437,7 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
     PVS_FAIL(PVS_ERR_UNSUPPORTED, "fused RootSIFT needs D <= %d (got %d)", ASSIGN_DCHUNK, cb->D);
   const int nt = assign_tiles_for(cb->K);
   if (cb->K_pad % (32 * nt) != 0) PVS_FAIL(PVS_ERR_INVALID, "codebook padding does not match the tile count");
-  AssignArgs a{d_desc, total, cb->D, ld, cb->d_cpad, cb->d_cnorm, cb->K_pad, cb->D_pad, d_labels};
+  AssignArgs a{d_desc, total, cb->D, ld, cb->d_cpad, cb->d_cnorm, cb->K_pad, cb->D_pad, d_labels, nullptr, nullptr, 0};
   const int esz = kind == PVS_DESC_U8_ROOTSIFT ? 1 : 4;
   // vector path: rows and 4-element groups are 16-B (f32) / 4-B (u8) aligned
   const bool vec = (cb->D % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_desc) % (4 * esz)) == 0);
@@ -216,6 +446,23 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
   const int64_t nblocks = (total + ASSIGN_ROWS - 1) / ASSIGN_ROWS;
   const int grid = (int)(nblocks < ctx->num_cu ? nblocks : ctx->num_cu);
   ScopedTimer tm(ctx, T_ASSIGN);
+  // ---- prefilter pass (fp16 MFMA) when the whole table has an fp16 copy; it leaves the near ties to the exact kernel
+  const bool pre = cb->d_c16 != nullptr && total >= 4096 && getenv("PVS_ASSIGN_EXACT_ONLY") == nullptr;
+  if (pre) {
+    const int64_t cap = (nblocks + grid - 1) / grid * ASSIGN_ROWS;   // a workgroup can list at most what it processes
+    char* ws = nullptr;
+    const size_t cnt_b = ((size_t)grid * 8 + 255) / 256 * 256;
+    PVS_TRY(ws_reserve(ctx, 6, cnt_b + (size_t)grid * cap * 8, reinterpret_cast<void**>(&ws)));
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(ws);
+    int64_t* rows = reinterpret_cast<int64_t*>(ws + cnt_b);
+    Assign16Args p{d_desc, total, cb->D, ld, static_cast<const _Float16*>(cb->d_c16), cb->d_cnorm, cb->K_pad, cb->D_pad16,
+                   cb->c16_shift, cb->cmax, d_labels, rows, cnt, cap};
+    const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4;
+    PVS_TRY(launch_assign16(ctx, p, kind, cb->K_pad / 32, vec, lds16, grid));
+    a.rows = rows;
+    a.nrows = cnt;
+    a.rows_cap = cap;
+  }
   switch (kind) {
     case PVS_DESC_F32: return launch_assign_kind<PVS_DESC_F32>(ctx, a, nt, vec, lds, grid);
     case PVS_DESC_F32_ROOTSIFT: return launch_assign_kind<PVS_DESC_F32_ROOTSIFT>(ctx, a, nt, vec, lds, grid);

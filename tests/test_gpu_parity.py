@@ -696,3 +696,31 @@ def test_filtered_topk_is_bit_identical_to_the_exact_path(gpu_ctx, tables, case)
         # the three all-zero rows score 0 against everything (all columns tie): they and the overflow case go to the exact path
         want_redone = {"overflow_to_exact": q.shape[0], "ties_and_near_ties": 3}.get(case, 0)
         assert st["redone_exact"] == want_redone, st
+
+
+@pytest.mark.parametrize("kind", [DESC_F32, DESC_U8_ROOTSIFT])
+def test_prefiltered_assignment_equals_the_exact_kernel(gpu_ctx, tables, kind, monkeypatch):
+    """K1 runs an fp16 MFMA prefilter and sends only near ties to the exact fp32 kernel: the labels must be those of the
+    exact kernel alone, for every descriptor -- incl. duplicated centres (exact ties), non-finite rows and zero rows."""
+    rng = np.random.default_rng(11)
+    proto = synth.sift_prototypes()
+    raw = synth.sift_like(300000, rng, proto)
+    C = tables["centroids"].copy()
+    C[17] = C[200]                                   # two identical centres: the first one must win, everywhere
+    cb = gpu_ctx.codebook(C)
+    if kind == DESC_F32:
+        x = synth.rootsift(raw)
+        x[5] = 0.0
+        x[6, 3] = np.nan
+        x[7, 9] = np.inf
+        x[8] = C[100]                                 # a descriptor sitting on a centre
+        x[9] = 0.5 * (C[3] + C[4])                    # and one between two centres
+    else:
+        x = raw.astype(np.uint8)
+    off = np.array([0, len(x)], np.int64)
+    monkeypatch.setenv("PVS_ASSIGN_EXACT_ONLY", "1")
+    _, exact = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
+    monkeypatch.delenv("PVS_ASSIGN_EXACT_ONLY")
+    _, pre = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
+    assert np.array_equal(exact, pre), np.argwhere(exact != pre)[:10]
+    assert not np.any(pre == 200)                    # never the later duplicate
