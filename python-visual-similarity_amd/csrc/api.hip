@@ -219,8 +219,12 @@ PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, 
       for (int d = 0; d < D; ++d) {
         const float v = centroids[(size_t)k * D + d] * sc;        // exact (power of two)
         const _Float16 hi = (_Float16)v;
-        h16[(size_t)k * cb->D_pad16 + d] = hi;
-        h16[tab + (size_t)k * cb->D_pad16 + d] = (_Float16)(v - (float)hi);   // v - hi is exact in fp32
+        // within a group of 16 dims the table is stored in the order the assignment kernel's lanes hold a descriptor:
+        // half-wave h keeps dims 4h..4h+3 and 8+4h..8+4h+3 (two adjacent float4 loads per lane pair)
+        const int g = d & 15, hh = (g >> 2) & 1, pos = 8 * hh + (g & 3) + 4 * (g >> 3);
+        const size_t o = (size_t)k * cb->D_pad16 + (d & ~15) + pos;
+        h16[o] = hi;
+        h16[tab + o] = (_Float16)(v - (float)hi);   // v - hi is exact in fp32
       }
     if (hipMalloc(&cb->d_c16, h16.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
     else if (hipMemcpyAsync(cb->d_c16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;

@@ -238,27 +238,30 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int64_t row = blk * ASSIGN_ROWS + wave * 32 + j;
     const bool rvalid = row < a.total;
-    // ---- this lane's half of the row: dims 16 t + 8 h .. + 7, t < 8
+    // ---- this lane's half of the row: of every 16 dims the four at 4h and the four at 8 + 4h (the lane pair (j, 0), (j, 1)
+    // reads 32 contiguous bytes per load; the fp16 tables are stored in the same order)
     float xf[8][8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) xf[t][q] = 0.f;
       if (t < nt && rvalid) {
-        const int d = 16 * t + 8 * h;
+        const int d = 16 * t + 4 * h;
         if constexpr (VEC) {
           if (d < a.D) {
             const float4 v = load4<KIND>(a.X, row, a.ld, d);
             xf[t][0] = v.x; xf[t][1] = v.y; xf[t][2] = v.z; xf[t][3] = v.w;
           }
-          if (d + 4 < a.D) {
-            const float4 v = load4<KIND>(a.X, row, a.ld, d + 4);
+          if (d + 8 < a.D) {
+            const float4 v = load4<KIND>(a.X, row, a.ld, d + 8);
             xf[t][4] = v.x; xf[t][5] = v.y; xf[t][6] = v.z; xf[t][7] = v.w;
           }
         } else {
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
+          for (int q = 0; q < 4; ++q) {
             if (d + q < a.D) xf[t][q] = load1<KIND>(a.X, row, a.ld, d + q);
+            if (d + 8 + q < a.D) xf[t][4 + q] = load1<KIND>(a.X, row, a.ld, d + 8 + q);
+          }
         }
       }
     }
