@@ -239,7 +239,10 @@ int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const 
   // qualify: the exact re-scoring reproduces the f32 MFMA kernel, so the exact path must itself take that kernel
   if (col_offset != 0) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: col_offset must be 0");
   if (nq <= 0 || N <= 0) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: empty input");
-  if (L % 8 != 0 || L < 8 || L > (int64_t)8 * 1024 * 1024 || reinterpret_cast<uintptr_t>(Q) % 16 || reinterpret_cast<uintptr_t>(DB) % 16)
+  // long rows (Fisher vectors, L = 262,400): the panels of the prefilter GEMM stop sharing L2 (the workgroups of an XCD drift
+  // apart over thousands of k-tiles) and it runs slower than the exact GEMM -- measured 174 vs 123 ms; not worth it there
+  if (L > 65536) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: rows longer than 65536 take the exact path");
+  if (L % 8 != 0 || L < 8 || reinterpret_cast<uintptr_t>(Q) % 16 || reinterpret_cast<uintptr_t>(DB) % 16)
     PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k needs 16-B aligned rows with L %% 8 == 0");
   if (k < 1 || k > 128 || N > 32768) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: k <= 128 and at most 32768 database rows per call");
   const bool same = (Q == DB) && (nq == N) && (invq == invdb);
