@@ -759,7 +759,10 @@ PVS_EXPORT int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const f
   float* d_val = reinterpret_cast<float*>(d_s + nrm + idxb);
   PVS_TRY(launch_row_inv_norms(ctx, dq, nq, L, invq));
   PVS_TRY(launch_row_inv_norms(ctx, ddb, N, L, invd));
-  PVS_TRY(pvs_cosine_topk_dev(ctx, dq, nq, ddb, N, L, invq, invd, k, 0, 0, d_idx, d_val));
+  // many queries: the filtered path returns the same lists (bit-identical) faster; it declines what does not qualify
+  const float* invd_use = same ? invq : invd;   // one pointer for both operands of a self-similarity: the symmetric kernel applies
+  if (nq >= 512) PVS_TRY(pvs_cosine_topk_filtered_dev(ctx, dq, nq, ddb, N, L, invq, invd_use, k, d_idx, d_val, nullptr));
+  else PVS_TRY(pvs_cosine_topk_dev(ctx, dq, nq, ddb, N, L, invq, invd_use, k, 0, 0, d_idx, d_val));
   PVS_HIP(hipMemcpyAsync(out_idx, d_idx, (size_t)nq * k * 8, hipMemcpyDeviceToHost, ctx->stream));
   PVS_HIP(hipMemcpyAsync(out_val, d_val, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
   PVS_HIP(hipStreamSynchronize(ctx->stream));
