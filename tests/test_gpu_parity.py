@@ -724,3 +724,21 @@ def test_prefiltered_assignment_equals_the_exact_kernel(gpu_ctx, tables, kind, m
     _, pre = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
     assert np.array_equal(exact, pre), np.argwhere(exact != pre)[:10]
     assert not np.any(pre == 200)                    # never the later duplicate
+
+
+@pytest.mark.parametrize("K,D", [(40, 100), (64, 30), (256, 128), (17, 16), (130, 72)])
+def test_prefiltered_assignment_odd_shapes(gpu_ctx, K, D, monkeypatch):
+    """Prefilter vs exact kernel on shapes that pad (K to 32 NT, D to 16) and on the scalar-load path (D % 4 != 0)."""
+    rng = np.random.default_rng(K * 1000 + D)
+    C = rng.normal(0.0, 1.0, size=(K, D)).astype(np.float32)
+    x = (C[rng.integers(0, K, 20000)] + rng.normal(0.0, 0.8, size=(20000, D))).astype(np.float32)
+    x[:50] *= 1e4                                   # rows far outside the table's scale
+    x[50:100] *= 1e-4
+    cb = gpu_ctx.codebook(C)
+    off = np.array([0, len(x)], np.int64)
+    monkeypatch.setenv("PVS_ASSIGN_EXACT_ONLY", "1")
+    _, exact = gpu_ctx.vlad_encode(cb, x, off, DESC_F32, return_labels=True)
+    monkeypatch.delenv("PVS_ASSIGN_EXACT_ONLY")
+    _, pre = gpu_ctx.vlad_encode(cb, x, off, DESC_F32, return_labels=True)
+    assert np.array_equal(exact, pre), np.argwhere(exact != pre)[:10]
+    assert np.array_equal(pre, orc.kmeans_predict(x, C)) or np.mean(pre != orc.kmeans_predict(x, C)) < 1e-3
