@@ -30,7 +30,15 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-l
 K_CLUSTERS, DIM, TOPK = 256, 128, 5
 
 
-def pmc_traffic(kernel_prefix):
+def _gemm_is_f16(name):
+    """gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, MODE, STAMP, F16, ...>: the 10th template argument"""
+    try:
+        return name.split("<", 1)[1].split(",")[9].strip() == "true"
+    except IndexError:
+        return False
+
+
+def pmc_traffic(kernel_prefix, keep=lambda name: True):
     """HBM-side bytes per launch of a kernel from the newest committed PMC summary (profiles/rNN_pmc_hbm.json,
     produced by profiles/summarize.py from separate rocprofv3 --pmc passes of this same command)."""
     import glob
@@ -40,7 +48,7 @@ def pmc_traffic(kernel_prefix):
     try:
         data = json.load(open(files[-1]))
         tot = [d["hbm_bytes_per_launch_corrected"] for name, d in data["kernels"].items()
-               if name.startswith(kernel_prefix) and "hbm_bytes_per_launch_corrected" in d]
+               if name.startswith(kernel_prefix) and keep(name) and "hbm_bytes_per_launch_corrected" in d]
         if tot:   # main + split-K partial + reduce launches together are one GEMM step
             return float(sum(tot)), os.path.basename(files[-1])
     except Exception:
@@ -433,7 +441,8 @@ def main():
         flop_per_launch = 2.0 * 128 * 128 * L * (t128 * (t128 + 1) / 2 + (world - 1) / 2.0 * t128 * t128) / launches_per_step
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flop_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
-    traffic, traffic_src = pmc_traffic("pvs::gemm_mfma_kernel")
+    # the exact f32 GEMM only (the same process also runs the fp16 prefilter GEMM of the filtered variant)
+    traffic, traffic_src = pmc_traffic("pvs::gemm_mfma_kernel", keep=lambda nm: not _gemm_is_f16(nm))
     if world != 1 or N != 8189 or filtered[0]:
         traffic, traffic_src = None, None             # the committed counters are for the default 1-GPU workload
     stages = {k: {"ms_total": round(v[0], 3), "launches": int(v[1]),
