@@ -742,3 +742,27 @@ def test_prefiltered_assignment_odd_shapes(gpu_ctx, K, D, monkeypatch):
     _, pre = gpu_ctx.vlad_encode(cb, x, off, DESC_F32, return_labels=True)
     assert np.array_equal(exact, pre), np.argwhere(exact != pre)[:10]
     assert np.array_equal(pre, orc.kmeans_predict(x, C)) or np.mean(pre != orc.kmeans_predict(x, C)) < 1e-3
+
+
+def test_multi_rank_bench_rehearsal():
+    """bench.py's N > 1 path end to end with two ranks sharing this GPU (gloo, host-staged collectives): image sharding,
+    exchange, block-pair scoring, all-to-all of candidate lists, merge -- each rank asserts that its lists equal the
+    single-GPU ranking bit for bit.  Everything but the RCCL transport of the measured configuration."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PVS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--images", "1030", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stderr.count("identical to the single-GPU ranking") == 2, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "REHEARSAL" in line["backend"]
