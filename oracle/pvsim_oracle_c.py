@@ -22,6 +22,7 @@ def lib():
                                       C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
         l.orc_retrieve.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_int]
+        l.orc_cosine_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         _lib = l
     return _lib
 
@@ -57,3 +58,16 @@ def retrieve(q, db, k, threads=0):
     if rc:
         raise MemoryError("oracle allocation failed")
     return idx, val
+
+
+def cosine_chain(a, b, inv_a, inv_b, pairs):
+    """The device's cosine score for the listed (i, j) pairs as its defined fp32 recurrence (see pvsim_oracle.c)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+    ia = None if inv_a is None else np.ascontiguousarray(inv_a, dtype=np.float32)
+    ib = None if inv_b is None else np.ascontiguousarray(inv_b, dtype=np.float32)
+    out = np.empty(pairs.shape[0], dtype=np.float32)
+    lib().orc_cosine_chain(a.ctypes.data, b.ctypes.data, a.shape[1], None if ia is None else ia.ctypes.data,
+                           None if ib is None else ib.ctypes.data, pairs.ctypes.data, pairs.shape[0], out.ctypes.data)
+    return out

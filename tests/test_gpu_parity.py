@@ -766,3 +766,28 @@ def test_multi_rank_bench_rehearsal():
     assert r.stderr.count("identical to the single-GPU ranking") == 2, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and "REHEARSAL" in line["backend"]
+
+
+@pytest.mark.parametrize("M,N,L", [(300, 300, 32768), (130, 257, 4096), (129, 700, 2600), (64, 64, 40)])
+def test_cosine_scores_are_the_defined_fp32_recurrence(gpu_ctx, M, N, L):
+    """Beyond the 2e-6 tolerance against the reference's BLAS result: the exact GEMM's score is a defined recurrence
+    (fma chain in the MFMA's k order, chains of 1024, ordered chain sums) that the C checker reproduces bit for bit --
+    in the symmetric, general, split-K and short-row (L < 1024, L % 32 != 0) cases alike."""
+    import pvsim_oracle_c as orc_c
+    rng = np.random.default_rng(M + N + L)
+    a = rng.standard_normal((M, L)).astype(np.float32)
+    same = M == N
+    b = a if same else rng.standard_normal((N, L)).astype(np.float32)
+    pairs = np.stack([rng.integers(0, M, 400), rng.integers(0, N, 400)], axis=1)
+    # unit norms through the raw GEMM entry point: the 1/||row|| factors come from a separate kernel with its own order
+    import torch
+    dev = torch.device("cuda", 0)
+    ta, tb = torch.from_numpy(a).to(dev), (None if same else torch.from_numpy(b).to(dev))
+    tb = ta if same else tb
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.cosine_dev(ta.data_ptr(), M, tb.data_ptr(), N, L, None, None, out.data_ptr(), N)
+    gpu_ctx.sync()
+    raw = out.cpu().numpy()
+    want = orc_c.cosine_chain(a, b, None, None, pairs)
+    assert np.array_equal(raw[pairs[:, 0], pairs[:, 1]].view(np.uint32), want.view(np.uint32))
