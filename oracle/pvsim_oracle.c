@@ -201,3 +201,37 @@ EXPORT int orc_cosine_chain(const float* A, const float* B, int64_t L, const flo
   }
   return 0;
 }
+
+/* K1 of the device as a defined recurrence: dot_j = fma chain over the dims in the exact kernel's MFMA order
+ * ((8t + e, 8t + 4 + e), e = 0..3), v_j = fmaf(-2, dot_j, |c_j|^2) with |c_j|^2 the sequential fp32 sum the library
+ * forms at table creation; strict '<' scan in ascending j.  labels[n]. */
+EXPORT int orc_assign_chain(const float* X, int64_t n, const float* C, int K, int D, int32_t* labels) {
+  float* cn = (float*)malloc(sizeof(float) * (size_t)K);
+  if (!cn) return 1;
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += C[(size_t)k * D + d] * C[(size_t)k * D + d];
+    cn[k] = s;
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    const float* x = X + (size_t)i * D;
+    float best = INFINITY;
+    int bi = 0;
+    for (int k = 0; k < K; ++k) {
+      const float* c = C + (size_t)k * D;
+      float acc = 0.f;
+      for (int b8 = 0; b8 < D; b8 += 8)
+        for (int e = 0; e < 4; ++e) {
+          const int k1 = b8 + e, k2 = b8 + 4 + e;
+          if (k1 < D) acc = fmaf(c[k1], x[k1], acc);
+          if (k2 < D) acc = fmaf(c[k2], x[k2], acc);
+        }
+      const float v = fmaf(-2.f, acc, cn[k]);
+      if (v < best) { best = v; bi = k; }
+    }
+    labels[i] = bi;
+  }
+  free(cn);
+  return 0;
+}

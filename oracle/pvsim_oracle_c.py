@@ -22,6 +22,7 @@ def lib():
                                       C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
         l.orc_retrieve.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_int]
+        l.orc_assign_chain.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         l.orc_cosine_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         _lib = l
     return _lib
@@ -71,3 +72,13 @@ def cosine_chain(a, b, inv_a, inv_b, pairs):
     lib().orc_cosine_chain(a.ctypes.data, b.ctypes.data, a.shape[1], None if ia is None else ia.ctypes.data,
                            None if ib is None else ib.ctypes.data, pairs.ctypes.data, pairs.shape[0], out.ctypes.data)
     return out
+
+
+def assign_chain(x, centroids):
+    """KMeans.predict as the device's exact kernel evaluates it (defined fp32 recurrence, see pvsim_oracle.c)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    c = np.ascontiguousarray(centroids, dtype=np.float32)
+    labels = np.empty(x.shape[0], dtype=np.int32)
+    if lib().orc_assign_chain(x.ctypes.data, x.shape[0], c.ctypes.data, c.shape[0], c.shape[1], labels.ctypes.data):
+        raise MemoryError("oracle allocation failed")
+    return labels
