@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--images", type=int, default=8189)
     ap.add_argument("--desc", choices=["f32", "u8"], default="f32",
                     help="descriptor rows in HBM: fp32 RootSIFT (default) or raw uint8 SIFT with fused RootSIFT")
-    ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim", "learn"], default="config2",
+    ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim", "learn", "corpus1m"], default="config2",
                     help="config2 = the headline line (default).  Side workloads (single GPU, same JSON shape, not the "
                          "headline): fisher = BASELINE configs[2] (Fisher D=512 K=256 n=196), vlad512 = the per-GPU share of "
                          "configs[3] (n=512 descriptors per image, encode only), fp16sim = configs[4] scaled to one GPU "
@@ -218,6 +218,67 @@ def side_workload(args):
                                  "frac": round(byt / dt / 1e9 / 8000.0, 4), "traffic": None,
                                  "assign_executed_f16_TFLOPs": round(3 * 2.0 * N * n * K_CLUSTERS * DIM / (st["assign"] * 1e-3) / 1e12, 1)},
                     "encode_algorithmic_GBps": round(byt / dt / 1e9, 1)})
+    elif args.workload == "corpus1m":
+        # BASELINE configs[3]/[4] at their real size on ONE GPU: N images x 512 raw SIFT-like uint8 descriptors are generated
+        # on the device chunk by chunk, VLAD-encoded (fused RootSIFT) and kept as fp16 rows with fp32 1/||.|| (65.5 GB at
+        # N = 1e6: the corpus the 8-GPU configuration shards); then 8192 queries rank against the whole corpus (fp16 MFMA
+        # GEMM, fp32 accumulate, fused top-10).  One pass, no warm-up repetitions of the corpus build.
+        from pvsim import synth
+        n, k, L, CH = 512, 10, K_CLUSTERS * DIM, 16384
+        cb = ctx.codebook(tables["centroids"])
+        proto = torch.from_numpy(synth.sift_prototypes().astype(np.float32)).to(dev)
+        db16 = torch.empty((N, L), dtype=torch.float16, device=dev)
+        inv = torch.empty((N,), dtype=torch.float32, device=dev)
+        enc = torch.empty((CH, L), dtype=torch.float32, device=dev)
+        off = (torch.arange(CH + 1, device=dev, dtype=torch.int64) * n).contiguous()
+        raw = torch.empty((CH * n, DIM), dtype=torch.uint8, device=dev)
+        ctx.timers_enable(True); ctx.timers_reset()
+        t_gen = t_enc = 0.0
+        for c0 in range(0, N, CH):
+            cn = min(CH, N - c0)
+            t0 = time.perf_counter()
+            for s0 in range(0, cn * n, 1 << 21):
+                e0 = min(cn * n, s0 + (1 << 21))
+                z = torch.randint(0, proto.shape[0], (e0 - s0,), generator=g, device=dev)
+                x = proto[z] * torch.exp(0.35 * torch.randn((e0 - s0, DIM), generator=g, device=dev)) + \
+                    4.8 * torch.rand((e0 - s0, DIM), generator=g, device=dev) ** 3
+                raw[s0:e0] = (x * (512.0 / x.norm(dim=1, keepdim=True).clamp_min(1e-9))).clamp_max(255.0).round().to(torch.uint8)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctx.vlad_encode_dev(cb, raw.data_ptr(), DESC_U8_ROOTSIFT, off.data_ptr(), cn, cn * n, enc.data_ptr(),
+                                d_inv_norm=inv[c0:].data_ptr())
+            ctx.f32_to_f16_dev(enc.data_ptr(), cn * L, db16[c0:].data_ptr())
+            ctx.sync()
+            t2 = time.perf_counter()
+            t_gen += t1 - t0
+            t_enc += t2 - t1
+            if (c0 // CH) % 8 == 0:
+                print(f"[corpus1m] {c0 + cn} / {N} images encoded", file=sys.stderr, flush=True)
+        tm_enc = ctx.timers()
+        nq = min(8192, N)
+        idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        val = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        ctx.timers_reset()
+        t0 = time.perf_counter()
+        ctx.cosine_topk_f16_dev(db16.data_ptr(), nq, db16.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(), k, 0, False,
+                                idx.data_ptr(), val.data_ptr())
+        ctx.sync()
+        t_ret = time.perf_counter() - t0
+        tm_ret = ctx.timers(); ctx.timers_enable(False)
+        assert np.array_equal(idx[:, 0].cpu().numpy(), np.arange(nq)), "self-retrieval failed"
+        flop = 2.0 * nq * N * L
+        out.update({"metric": "images/sec VLAD-encoded into a resident fp16 corpus, then query rows/sec against it (BASELINE configs[3]/[4] on one GPU)",
+                    "value": round(N / t_enc, 1), "unit": "images/s", "ms_per_step": round(t_enc * 1e3, 1), "steps": 1, "warmup": 0,
+                    "dtype": "f32 encode, f16 retrieval operands", "scaling": "weak",
+                    "config": {"workload": f"{N} images x {n} uint8 descriptors -> fp16 corpus ({N * L * 2 / 1e9:.1f} GB resident); "
+                                           f"{nq} queries x {N} rows, top-{k}"},
+                    "corpus_build": {"encode_s": round(t_enc, 3), "generate_s": round(t_gen, 1),
+                                     "stages_ms": {kk: round(v[0], 1) for kk, v in tm_enc.items() if v[1]}},
+                    "retrieval": {"seconds": round(t_ret, 3), "queries_per_s": round(nq / t_ret, 1),
+                                  "algorithmic_TFLOPs": round(flop / t_ret / 1e12, 1),
+                                  "stages_ms": {kk: round(v[0], 1) for kk, v in tm_ret.items() if v[1]}},
+                    "hbm_resident_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)})
     elif args.workload == "learn":
         # vocabulary training: one "step" = k-means++ seeding + 10 Lloyd iterations (K=256)
         # and 5 EM iterations of a K=256 diagonal GMM over args.images x 64 RootSIFT descriptors
