@@ -795,3 +795,32 @@ def test_cosine_scores_are_the_defined_fp32_recurrence(gpu_ctx, M, N, L):
     raw = out.cpu().numpy()
     want = orc_c.cosine_chain(a, b, None, None, pairs)
     assert np.array_equal(raw[pairs[:, 0], pairs[:, 1]].view(np.uint32), want.view(np.uint32))
+
+
+def test_notebook_shapes_known_answers():
+    """The reference has no tests; its executed notebooks record output shapes:
+    getting_started: VLAD K=32 on PCA-64 SIFT -> (N, 2048), Fisher -> (N, 4128) = 32 + 2*32*64;
+    pipeline: VGG16 deep features (514-D incl. coordinates): VLAD K=256 -> (1, 131584) = 256*514, Fisher on the PCA-257
+    features -> (1, 131840) = 256 + 2*256*257, Pipeline([VLAD, Fisher]) -> (5, 263424)."""
+    from pvsim.encoders import VLADEncoder, FisherVectorEncoder, Pipeline
+    from pvsim.features import Lambda
+    from pvsim.models import KMeansModel, GMMModel, PCAModel
+    rng = np.random.default_rng(4)
+    sift = Lambda(lambda im: im.astype(np.float32), 128)
+    imgs = [rng.integers(0, 255, size=(int(n), 128)) for n in (60, 75, 90, 64, 80)]
+    pca64 = PCAModel(np.linalg.qr(rng.standard_normal((128, 64)))[0].T, rng.random(128))
+    v = VLADEncoder(sift, kmeans_model=KMeansModel(rng.random((32, 64))), pca=pca64).encode(imgs)
+    f = FisherVectorEncoder(sift, gmm_model=GMMModel(np.full(32, 1 / 32), rng.random((32, 64)), np.ones((32, 64))), pca=pca64).encode(imgs)
+    assert v.shape == (5, 2048) and v.dtype == np.float32
+    assert f.shape == (5, 4128) and f.dtype == np.float64
+    deep = Lambda(lambda im: im.astype(np.float32) / 64.0, 514)
+    dimgs = [rng.integers(0, 255, size=(196, 514)) for _ in range(5)]
+    pca257 = PCAModel(np.linalg.qr(rng.standard_normal((514, 257)))[0].T, rng.random(514))
+    ve = VLADEncoder(deep, kmeans_model=KMeansModel(rng.random((256, 514))))
+    fe = FisherVectorEncoder(deep, gmm_model=GMMModel(np.full(256, 1 / 256), rng.random((256, 257)), np.ones((256, 257))), pca=pca257)
+    assert ve.encode(dimgs[:1]).shape == (1, 131584)
+    assert fe.encode(dimgs[:1]).shape == (1, 131840)
+    p = Pipeline([ve, fe]).encode(dimgs)
+    assert p.shape == (5, 263424)
+    s = ve.similarity_score(dimgs[:2], dimgs[2:])
+    assert s.shape == (2, 3) and s.dtype == np.float32
