@@ -195,7 +195,8 @@ PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, 
     for (int d = 0; d < D; ++d) {
       const float v = centroids[(size_t)k * D + d];
       pad[(size_t)k * cb->D_pad + d] = v;
-      s += v * v;
+      const float sq = v * v;   // two statements: a product rounded to fp32, then the add (never contracted into an fma)
+      s += sq;
     }
     cn[k] = s;
   }

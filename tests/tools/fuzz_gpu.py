@@ -1,0 +1,138 @@
+"""Randomised parity sweep on the GPU (run by hand: python tests/tools/fuzz_gpu.py [seconds] [seed]).
+Random shapes / kinds / normalisation parameters for VLAD, Fisher, cosine, top-k, filtered top-k and the prefiltered
+assignment, each checked against the oracle or against the exact device path.  Prints the first failing case."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+torch.cuda.init()      # before the engine opens the device (the other order leaves torch without a GPU on the test box)
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path[:0] = [REPO, os.path.join(REPO, "python-visual-similarity_amd"), os.path.join(REPO, "oracle")]
+import pvsim                      # noqa: E402
+import pvsim_oracle as orc        # noqa: E402
+import pvsim_oracle_c as orc_c    # noqa: E402
+from pvsim.engine import DESC_F32, DESC_F32_ROOTSIFT, DESC_U8_ROOTSIFT  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+ctx = pvsim.Context(0)
+t_end = time.time() + budget
+counts = {}
+
+
+def ragged(n_img, lo, hi):
+    return [int(v) for v in rng.integers(lo, hi, n_img)]
+
+
+def case_vlad():
+    K = int(rng.choice([1, 7, 16, 33, 64, 100, 256, 300]))
+    D = int(rng.choice([2, 8, 30, 64, 100, 128, 130, 200]))
+    kind = int(rng.choice([DESC_F32, DESC_F32_ROOTSIFT, DESC_U8_ROOTSIFT])) if D <= 128 else DESC_F32
+    counts_ = ragged(int(rng.integers(1, 6)), 0, int(rng.choice([5, 300, 6000])))
+    C = rng.random((K, D)).astype(np.float32) * (0.2 if kind != DESC_F32 else 1.0)
+    if kind == DESC_F32:
+        descs = [(C[rng.integers(0, K, n)] + 0.3 * rng.standard_normal((n, D))).astype(np.float32) for n in counts_]
+        ref_in = descs
+    else:
+        raws = [rng.integers(0, 256, size=(n, D)).astype(np.uint8) for n in counts_]
+        descs = raws if kind == DESC_U8_ROOTSIFT else [r.astype(np.float32) for r in raws]
+        ref_in = [orc.rootsift(r.astype(np.float32)) for r in raws]
+    power = float(rng.choice([1.0, 0.5, 0.3]))
+    order = float(rng.choice([2.0, 1.0, 3.0]))
+    packed, off = pvsim.pack_descriptors(descs, D, np.uint8 if kind == DESC_U8_ROOTSIFT else np.float32)
+    cb = ctx.codebook(C)
+    v, labels = ctx.vlad_encode(cb, packed, off, kind, power=power, norm_order=order, return_labels=True)
+    cb.close()
+    allx = np.concatenate(ref_in) if sum(counts_) else np.zeros((0, D), np.float32)
+    want_labels = orc_c.assign_chain(allx, C) if len(allx) else np.zeros(0, np.int32)
+    assert np.array_equal(labels, want_labels), ("vlad labels", K, D, kind, counts_)
+    ref = np.stack([orc.vlad_normalise(orc.vlad_aggregate(x, want_labels[o:o + len(x)], C), power, order, 1e-9).reshape(-1)
+                    for x, o in zip(ref_in, np.cumsum([0] + counts_[:-1]))])
+    assert np.allclose(v, ref, rtol=0, atol=3e-6), ("vlad values", K, D, kind, counts_, power, order, float(np.abs(v - ref).max()))
+
+
+def case_fisher():
+    K = int(rng.choice([1, 5, 32, 64, 256, 300]))
+    D = int(rng.choice([2, 16, 64, 100, 128, 257]))
+    counts_ = ragged(int(rng.integers(1, 5)), 1, int(rng.choice([4, 200, 1500])))
+    mu = rng.normal(0, 1, (K, D))
+    cov = rng.uniform(0.05, 2.0, (K, D))
+    w = rng.random(K) + 0.1
+    w /= w.sum()
+    descs = [(mu[rng.integers(0, K, n)] + rng.standard_normal((n, D)) * 0.7).astype(np.float32) for n in counts_]
+    power = float(rng.choice([0.5, 1.0, 0.7]))
+    order = float(rng.choice([2.0, 1.0]))
+    g = ctx.gmm(w, mu, cov)
+    packed, off = pvsim.pack_descriptors(descs, D, np.float32)
+    f = ctx.fisher_encode(g, packed, off, power=power, norm_order=order)
+    g.close()
+    ref = orc.fisher_encode(descs, w, mu, cov, power=power, norm_order=order)
+    assert np.allclose(f, ref, rtol=0, atol=2e-9), ("fisher", K, D, counts_, power, order, float(np.abs(f - ref).max()))
+
+
+def case_cosine_topk():
+    M, N = int(rng.integers(1, 400)), int(rng.integers(1, 3000))
+    L = int(rng.choice([2, 24, 40, 128, 1000, 1024, 2600, 4096, 32768]))
+    same = bool(rng.integers(0, 2))
+    a = rng.standard_normal((M, L)).astype(np.float32)
+    b = a if same else rng.standard_normal((N, L)).astype(np.float32)
+    if same:
+        N = M
+    s = ctx.cosine(a, b)
+    ref = orc.cosine_similarity(a, b)
+    assert np.allclose(s, ref, rtol=0, atol=3e-6), ("cosine", M, N, L, same, float(np.abs(s - ref).max()))
+    k = int(rng.integers(1, min(N, 40) + 1))
+    idx, val = ctx.cosine_topk(a, b, k)
+    order = np.argsort(-s, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(idx, order), ("topk", M, N, L, k)
+
+
+def case_filtered():
+    nq, N = int(rng.integers(1, 700)), int(rng.integers(2, 4000))
+    L = int(rng.choice([8, 64, 1000, 1024, 2600, 4096, 8192]))
+    same = bool(rng.integers(0, 2))
+    base = rng.standard_normal((N, L)).astype(np.float32) * float(rng.choice([1e-3, 1.0, 1e3]))
+    if rng.integers(0, 2):
+        base[rng.integers(0, N, N // 4)] = base[rng.integers(0, N, N // 4)]      # duplicate rows
+    db = torch.from_numpy(base).cuda()
+    q = db if same else torch.from_numpy((base[rng.integers(0, N, nq)] * (1 + 1e-3 * rng.standard_normal((nq, L)))).astype(np.float32)).cuda()
+    nq = q.shape[0]
+    k = int(rng.integers(1, min(N, 30) + 1))
+    iq = torch.empty(nq, dtype=torch.float32, device="cuda")
+    idb = iq if same else torch.empty(N, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.row_inv_norms_dev(q.data_ptr(), nq, L, iq.data_ptr())
+    if not same:
+        ctx.row_inv_norms_dev(db.data_ptr(), N, L, idb.data_ptr())
+    res = []
+    for filt in (0, 1):
+        idx = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        val = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        if filt:
+            ctx.cosine_topk_filtered_dev(q.data_ptr(), nq, db.data_ptr(), N, L, iq.data_ptr(), idb.data_ptr(), k, idx.data_ptr(), val.data_ptr())
+        else:
+            ctx.cosine_topk_dev(q.data_ptr(), nq, db.data_ptr(), N, L, iq.data_ptr(), idb.data_ptr(), k, 0, False, idx.data_ptr(), val.data_ptr())
+        ctx.sync()
+        res.append((idx.cpu().numpy(), val.cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]), ("filtered idx", nq, N, L, k, same)
+    assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32)), ("filtered val", nq, N, L, k, same)
+
+
+cases = [case_vlad, case_fisher, case_cosine_topk, case_filtered]
+i = 0
+while time.time() < t_end:
+    fn = cases[i % len(cases)]
+    i += 1
+    try:
+        fn()
+    except AssertionError as e:
+        print("FAIL", fn.__name__, "seed", seed, "iteration", i, e.args[0] if e.args else "")
+        sys.exit(1)
+    counts[fn.__name__] = counts.get(fn.__name__, 0) + 1
+print("fuzz ok", counts)
