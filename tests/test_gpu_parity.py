@@ -824,3 +824,50 @@ def test_notebook_shapes_known_answers():
     assert p.shape == (5, 263424)
     s = ve.similarity_score(dimgs[:2], dimgs[2:])
     assert s.shape == (2, 3) and s.dtype == np.float32
+
+
+def test_config2_full_size_topk_against_the_restatement(gpu_ctx, tables):
+    """SURVEY.md section 8d, config 2 at its full size: 8189 images (the bench generator, on the device), VLAD K=256,
+    8189 x 8189 retrieval with k = 5 and k = 100, compared with the NumPy restatement (sklearn normalize + BLAS product +
+    stable ranking) on a 512-query subsample.  Adjacent scores at rank ~100 are ~6e-5 apart, so an fp32 evaluation in another summation
+    order may swap near ties: ranks are compared through their scores (3e-6), the k = 5 lists exactly."""
+    import sys
+    import torch
+    from conftest import REPO
+    sys.path.insert(0, REPO)
+    import bench
+    dev = torch.device("cuda", 0)
+    N, L = 8189, 32768
+    raw, offsets = bench.make_corpus(N, 1235, dev)
+    d_off = torch.from_numpy(offsets).to(dev)
+    enc = torch.empty((N, L), dtype=torch.float32, device=dev)
+    inv = torch.empty((N,), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    cb = gpu_ctx.codebook(tables["centroids"])
+    gpu_ctx.vlad_encode_dev(cb, raw.data_ptr(), DESC_U8_ROOTSIFT, d_off.data_ptr(), N, int(offsets[-1]), enc.data_ptr(),
+                            d_inv_norm=inv.data_ptr())
+    gpu_ctx.sync()
+    rng = np.random.default_rng(5)
+    sub = np.sort(rng.choice(N, 512, replace=False))
+    h_enc = enc.cpu().numpy()
+    sims = orc.cosine_similarity(h_enc[sub], h_enc)
+    for k in (5, 100):
+        idx = torch.empty((N, k), dtype=torch.int64, device=dev)
+        val = torch.empty((N, k), dtype=torch.float32, device=dev)
+        fidx, fval = torch.empty_like(idx), torch.empty_like(val)
+        torch.cuda.synchronize()
+        gpu_ctx.cosine_topk_dev(enc.data_ptr(), N, enc.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(), k, 0, False,
+                                idx.data_ptr(), val.data_ptr())
+        st = gpu_ctx.cosine_topk_filtered_dev(enc.data_ptr(), N, enc.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(), k,
+                                              fidx.data_ptr(), fval.data_ptr())
+        gpu_ctx.sync()
+        assert st["filtered"] and torch.equal(idx, fidx) and torch.equal(val.view(torch.int32), fval.view(torch.int32))
+        ridx, rval = orc.topk(sims, k)
+        di, dv = idx.cpu().numpy()[sub], val.cpu().numpy()[sub]
+        np.testing.assert_allclose(dv, rval, rtol=0, atol=3e-6)   # NumPy's own self-scores reach 1.000001..1.000003 at L = 32768
+        if k == 5:
+            assert np.array_equal(di, ridx)
+        else:
+            agree = (di == ridx).mean()
+            assert agree > 0.99, agree                      # the rest are swaps of near ties (scores equal to 3e-6, above)
+        assert np.array_equal(di[:, 0], sub)
