@@ -38,6 +38,19 @@ def _gemm_is_f16(name):
         return False
 
 
+def pmc_mfma_busy(kernel_prefix, keep=lambda name: True):
+    """MFMA pipe utilisation of a kernel from the newest committed PMC summary (launch-weighted over its variants)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm.json")))
+    try:
+        data = json.load(open(files[-1]))
+        v = [d["mfma_pipe_busy_frac"] for name, d in data["kernels"].items()
+             if name.startswith(kernel_prefix) and keep(name) and "mfma_pipe_busy_frac" in d]
+        return max(v) if v else None      # the main launch (the split-K partial / reduce launches are tiny)
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel_prefix, keep=lambda name: True):
     """HBM-side bytes per launch of a kernel from the newest committed PMC summary (profiles/rNN_pmc_hbm.json,
     produced by profiles/summarize.py from separate rocprofv3 --pmc passes of this same command)."""
@@ -557,6 +570,8 @@ def main():
                      "peak": 2500.0 if filtered[0] else FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / (2500.0 if filtered[0] else FP32_MFMA_PEAK_TFLOPS), 4),
                      "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flop_per_launch,
+                     "mfma_pipe_busy_frac": None if (world != 1 or N != 8189 or filtered[0]) else
+                     pmc_mfma_busy("pvs::gemm_mfma_kernel", keep=lambda nm: not _gemm_is_f16(nm)),
                      "algorithmic_flop_per_launch": alg_flop,
                      "algorithmic_equiv_TFLOPs": round(alg_flop / (gemm_avg_ms * 1e-3) / 1e12, 2) if gemm_n else None, "avg_launch_ms": round(gemm_avg_ms, 4)},
         "stages": stages,

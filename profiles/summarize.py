@@ -41,6 +41,16 @@ for k, d in out.items():
         # gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads -> doubled
         # (MI355X_MICROARCH.md, section HBM); WRITE_SIZE is exact for 16-B-per-lane stores.
         d["hbm_bytes_per_launch_corrected"] = (2.0 * f_ + w_) * 1024.0
+# MFMA pipe utilisation: busy cycles of the matrix pipes / (4 SIMDs x busy CU cycles), summed over the launches of a kernel
+path = one("mfma/**/*_counter_collection.csv")
+if path:
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(path)):
+        if "pvs::" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]] += float(r["Counter_Value"])
+    for k, d in acc.items():
+        if d.get("SQ_BUSY_CU_CYCLES"):
+            out.setdefault(k, {})["mfma_pipe_busy_frac"] = round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * d["SQ_BUSY_CU_CYCLES"]), 4)
 if out:
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
                           "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
