@@ -871,3 +871,25 @@ def test_config2_full_size_topk_against_the_restatement(gpu_ctx, tables):
             agree = (di == ridx).mean()
             assert agree > 0.99, agree                      # the rest are swaps of near ties (scores equal to 3e-6, above)
         assert np.array_equal(di[:, 0], sub)
+
+
+def test_learn_from_raw_sift_descriptors(tables):
+    """learn_from_descriptors(rootsift=True): raw uint8 SIFT rows are transformed on the device exactly as encode does, so a
+    vocabulary learnt from them equals one learnt from the host-side RootSIFT rows (same start, same iterations)."""
+    from pvsim.encoders import VLADEncoder
+    from pvsim.features import Lambda
+    from pvsim.models import KMeansModel
+    rng = np.random.default_rng(8)
+    raw = synth.sift_like(12000, rng).astype(np.uint8)
+    x = synth.rootsift(raw.astype(np.float32))
+    c0 = x[rng.choice(len(x), 32, replace=False)]
+    fx = Lambda(lambda im: im.astype(np.float32), 128)
+    a = VLADEncoder(fx, kmeans_model=KMeansModel(c0))
+    b = VLADEncoder(fx, kmeans_model=KMeansModel(c0))
+    a.learn_from_descriptors(raw, n_clusters=32, rootsift=True, init=c0, n_init=1, max_iter=4, tol=0.0)
+    b.learn_from_descriptors(x, n_clusters=32, init=c0, n_init=1, max_iter=4, tol=0.0)
+    assert np.array_equal(a.clustering_model.cluster_centers_, b.clustering_model.cluster_centers_)
+    assert np.array_equal(a.clustering_model.labels_, b.clustering_model.labels_)
+    ref_c, ref_l, _, _ = orc.kmeans_lloyd(x, c0, max_iter=4, tol=0.0)
+    assert np.mean(ref_l != a.clustering_model.labels_) < 2e-3          # near ties may flip (fp32 sums in another order)
+    np.testing.assert_allclose(a.clustering_model.cluster_centers_, ref_c, rtol=0, atol=2e-4)
