@@ -85,7 +85,8 @@ def case_cosine_topk():
         N = M
     s = ctx.cosine(a, b)
     ref = orc.cosine_similarity(a, b)
-    assert np.allclose(s, ref, rtol=0, atol=3e-6), ("cosine", M, N, L, same, float(np.abs(s - ref).max()))
+    # NumPy normalises the rows first and then multiplies: its own self-scores reach 1.000003 at L = 32768
+    assert np.allclose(s, ref, rtol=0, atol=5e-6 if L >= 32768 else 3e-6), ("cosine", M, N, L, same, float(np.abs(s - ref).max()))
     k = int(rng.integers(1, min(N, 40) + 1))
     idx, val = ctx.cosine_topk(a, b, k)
     order = np.argsort(-s, axis=1, kind="stable")[:, :k]
