@@ -619,36 +619,48 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
           acc[r][q] = (ch > 0 && in) ? out_img[(int64_t)k * D + d0 + q] : 0.f;  // continue a long image
         }
       }
-      for (int p = s; p < e; ++p) {
-        const int64_t row = cbase + order[p];
-        float x[NREG][VW];
+      // members in descriptor order; the loads of up to PF rows are issued before the first of them is added (one load in
+      // flight per lane group leaves the kernel latency-bound), the additions themselves stay strictly in order
+      constexpr int PF = NREG <= 2 ? 4 : 2;
+      for (int p0 = s; p0 < e; p0 += PF) {
+        float x[PF][NREG][VW];
 #pragma unroll
-        for (int r = 0; r < NREG; ++r) {
-          const int d0 = (r * GROUP + gl) * VW;
-          if constexpr (VW == 4) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d0 < D) t = load4<KIND>(a.X, row, a.ld, d0);
-            x[r][0] = t.x; x[r][1] = t.y; x[r][2] = t.z; x[r][3] = t.w;
-          } else {
-            x[r][0] = d0 < D ? load1<KIND>(a.X, row, a.ld, d0) : 0.f;
+        for (int u = 0; u < PF; ++u) {
+          const bool live = p0 + u < e;
+          const int64_t row = cbase + order[live ? p0 + u : p0];
+#pragma unroll
+          for (int r = 0; r < NREG; ++r) {
+            const int d0 = (r * GROUP + gl) * VW;
+            if constexpr (VW == 4) {
+              float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (live && d0 < D) t = load4<KIND>(a.X, row, a.ld, d0);
+              x[u][r][0] = t.x; x[u][r][1] = t.y; x[u][r][2] = t.z; x[u][r][3] = t.w;
+            } else {
+              x[u][r][0] = (live && d0 < D) ? load1<KIND>(a.X, row, a.ld, d0) : 0.f;
+            }
           }
         }
-        if constexpr (DescTraits<KIND>::rootsift) {
-          float sm = 0.f;
 #pragma unroll
-          for (int r = 0; r < NREG; ++r)
+        for (int u = 0; u < PF; ++u) {
+          if (p0 + u < e) {   // uniform over the lane group
+            if constexpr (DescTraits<KIND>::rootsift) {
+              float sm = 0.f;
 #pragma unroll
-            for (int q = 0; q < VW; ++q) sm += x[r][q];
-          sm = wave_sum_xor(sm, GROUP);
+              for (int r = 0; r < NREG; ++r)
 #pragma unroll
-          for (int r = 0; r < NREG; ++r)
+                for (int q = 0; q < VW; ++q) sm += x[u][r][q];
+              sm = wave_sum_xor(sm, GROUP);
 #pragma unroll
-            for (int q = 0; q < VW; ++q) x[r][q] = rootsift_apply(x[r][q], sm);
+              for (int r = 0; r < NREG; ++r)
+#pragma unroll
+                for (int q = 0; q < VW; ++q) x[u][r][q] = rootsift_apply(x[u][r][q], sm);
+            }
+#pragma unroll
+            for (int r = 0; r < NREG; ++r)
+#pragma unroll
+              for (int q = 0; q < VW; ++q) acc[r][q] += (x[u][r][q] - c[r][q]);
+          }
         }
-#pragma unroll
-        for (int r = 0; r < NREG; ++r)
-#pragma unroll
-          for (int q = 0; q < VW; ++q) acc[r][q] += (x[r][q] - c[r][q]);
       }
 
       if (!last) {
