@@ -409,7 +409,15 @@ def main():
         else:
             fn(out_t, in_t)
 
-    ctx = pvsim.Context(local)
+    # N > 1: ONE stream for the engine, torch and (through torch's stream semantics) RCCL -- the step then needs no host
+    # synchronisation between encode, exchange and retrieval, and the CPU can run ahead of the many small launches
+    one_stream = world > 1
+    if one_stream:
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(side)
+        ctx = pvsim.Context(local, stream=side.cuda_stream)
+    else:
+        ctx = pvsim.Context(local)
     tables = np.load(os.path.join(REPO, "tests", "golden", "tables_k256_d128.npz"), allow_pickle=False)
     cb = ctx.codebook(tables["centroids"])
 
@@ -441,25 +449,29 @@ def main():
 
     from pvsim import distributed as pd
     score_block = pd.device_score_block(ctx)
-    ops = pd.DeviceOps(ctx)
+    ops = pd.DeviceOps(ctx, same_stream=one_stream)
 
     def a2a(out_t, in_t):
         coll(dist.all_to_all_single, out_t, in_t)
-        torch.cuda.current_stream().synchronize()
+        if not one_stream:
+            torch.cuda.current_stream().synchronize()
 
     def new_tensor(shape, dtype, fill):
         t_ = torch.full(shape, fill, dtype=dtype, device=dev)
-        torch.cuda.current_stream().synchronize()      # visible to the context's stream
+        if not one_stream:
+            torch.cuda.current_stream().synchronize()      # visible to the context's stream
         return t_
 
     def step():
         ctx.vlad_encode_dev(cb, desc.data_ptr(), kind, d_off.data_ptr(), n_loc, total_desc, enc_loc.data_ptr(),
                             d_inv_norm=inv_loc.data_ptr())
         if world > 1:
-            ctx.sync()                                   # encode (ctx stream) -> collective (torch stream)
+            if not one_stream:
+                ctx.sync()                               # encode (ctx stream) -> collective (torch stream)
             coll(dist.all_gather_into_tensor, enc_all, enc_loc)
             coll(dist.all_gather_into_tensor, inv_all, inv_loc)
-            torch.cuda.current_stream().synchronize()
+            if not one_stream:
+                torch.cuda.current_stream().synchronize()
         if world == 1 and filtered[0]:
             filt_stats[0] = ctx.cosine_topk_filtered_dev(enc_loc.data_ptr(), n_loc, enc_loc.data_ptr(), n_loc, L, inv_loc.data_ptr(),
                                                          inv_loc.data_ptr(), TOPK, idx.data_ptr(), val.data_ptr())

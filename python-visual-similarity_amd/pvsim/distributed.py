@@ -95,8 +95,12 @@ def device_score_block(ctx):
 class DeviceOps:
     """The four device operations of the scheme, bound to a pvsim.Context (tests plug in CPU stand-ins)."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, same_stream: bool = False):
+        """same_stream=True: the context was created on the stream the caller's tensors / collectives use (e.g.
+        pvsim.Context(dev, stream=torch.cuda.current_stream().cuda_stream)), so no host synchronisation is needed
+        between this object's launches and the caller's."""
         self.ctx = ctx
+        self.same_stream = same_stream
 
     def sym_topk(self, q, n, inv, k, col_offset, idx, val):
         self.ctx.cosine_topk_dev(q.data_ptr(), n, q.data_ptr(), n, q.shape[1], inv.data_ptr(), inv.data_ptr(), k,
@@ -113,7 +117,8 @@ class DeviceOps:
         self.ctx.topk_merge_dev(idx_lists.data_ptr(), val_lists.data_ptr(), n_lists, nq, k, idx.data_ptr(), val.data_ptr())
 
     def sync(self):
-        self.ctx.sync()
+        if not self.same_stream:
+            self.ctx.sync()
 
 
 def _rows(n_total, world, r):
