@@ -99,18 +99,27 @@ static int build_plan(pvs_ctx* ctx, int which, int tiles_m, int tiles_n, bool sy
       }
     }
     const int total = (int)t.size();
-    const int rem = total % slots;
+    // How to cut the work into launches.  One tile takes the same time T whether the chip is full or not, so a problem of
+    // few tiles (a rank's share in the multi-GPU scheme, a query batch) is fast only when its tiles are split along K into
+    // s slices (whole 1024-k chains each; the reduce adds the chain images in chain order, so the scores do not change).
+    // Cost in units of T:  rounds(blocks) * (1/s + eps) + the reduce's traffic;  candidates: full rounds unsplit + the last
+    // partial round split (A), or every tile split (B).
+    const double eps = 0.02, red = 3.0e-4;
+    auto rounds = [&](long blocks) { return (double)((blocks + slots - 1) / slots); };
+    const int full = total / slots, rem = total % slots;
+    double best = rounds(total);            // nothing split
     P.n_main = total;
     P.n_tail = 0;
     P.splitk = 1;
-    if (rem > 0 && rem <= slots / 2) {
-      // the last (or only) round would leave >= half the chip idle: its tiles are split along K over `s` blocks
-      // each (deterministic partial sums + ordered reduce).  Small problems (few queries) run entirely this way.
-      int s = 2;
-      while (s * 2 <= 16 && rem * s * 2 <= slots) s *= 2;
-      P.n_main = total - rem;
-      P.n_tail = rem;
-      P.splitk = s;
+    for (int sk = 2; sk <= 32; sk *= 2) {
+      if (rem > 0) {
+        const double a = full + rounds((long)rem * sk) * (1.0 / sk + eps) + red * rem;
+        if (a < best - 1e-9) { best = a; P.n_main = total - rem; P.n_tail = rem; P.splitk = sk; }
+      }
+      if (total < 4 * slots) {
+        const double b = rounds((long)total * sk) * (1.0 / sk + eps) + red * total;
+        if (b < best - 1e-9) { best = b; P.n_main = 0; P.n_tail = total; P.splitk = sk; }
+      }
     }
     if (P.cap < t.size()) {
       PVS_HIP(hipStreamSynchronize(ctx->stream));
