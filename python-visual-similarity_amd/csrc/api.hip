@@ -686,6 +686,13 @@ PVS_EXPORT int pvs_cosine_topk_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, c
   return cosine_topk_impl(ctx, d_Q, nq, d_DB, N, L, false, d_inv_q, d_inv_db, k, col_offset, merge, d_idx, d_val);
 }
 
+namespace pvs {
+int cosine_topk_exact(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L, const float* d_inv_q,
+                      const float* d_inv_db, int k, int64_t* d_idx, float* d_val) {
+  return cosine_topk_impl(ctx, d_Q, nq, d_DB, N, L, false, d_inv_q, d_inv_db, k, 0, 0, d_idx, d_val);
+}
+}  // namespace pvs
+
 // Exact top-k through the fp16 prefilter + exact re-scoring (filter.hip); inputs that do not qualify take the plain path.
 PVS_EXPORT int pvs_cosine_topk_filtered_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L,
                                             const float* d_inv_q, const float* d_inv_db, int k, int64_t* d_idx, float* d_val,

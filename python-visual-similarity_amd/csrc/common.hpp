@@ -140,6 +140,9 @@ int launch_cosine_f16(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int
 int launch_f32_to_f16(pvs_ctx* ctx, const float* src, int64_t n, void* dst);
 int launch_cosine_f16_bounded(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
                               const float* invb, float* out, int64_t ldo);
+// the plain exact path for device operands (api.hip): f32 GEMM panels + select over all database rows
+int cosine_topk_exact(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L, const float* d_inv_q,
+                      const float* d_inv_db, int k, int64_t* d_idx, float* d_val);
 // exact top-k through an fp16 prefilter + exact re-scoring (filter.hip); returns PVS_ERR_UNSUPPORTED when the inputs
 // do not qualify (the caller then runs the plain exact path)
 int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L,

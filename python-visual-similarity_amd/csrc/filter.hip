@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void filter_rows_to_f16_kernel(const float* __
 // top-k merge kernel reads.  count[q] may exceed cap (overflow: that query is redone by the exact path).
 __global__ __launch_bounds__(256) void filter_collect_kernel(const float* __restrict__ S, int64_t nq, int64_t ncols, int64_t ld,
                                                              const int64_t* __restrict__ aidx, const float* __restrict__ aval,
-                                                             int k, float margin, int cap, int64_t col_offset,
+                                                             int k, float margin, int cap, int64_t col_offset, int first,
                                                              int64_t* __restrict__ cand_idx, int* __restrict__ count,
                                                              unsigned long long* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256) void filter_collect_kernel(const float* __rest
   if (q >= nq) return;
   const bool full = aidx[q * k + k - 1] >= 0;                       // fewer than k columns: everything is a candidate
   const float thr = full ? aval[q * k + k - 1] - margin : -INFINITY;
-  int base = 0;
+  // database panels after the first append to the query's list; the threshold is the k-th best seen SO FAR, which can only
+  // be lower than the final one, so the test stays a superset test
+  int base = first ? 0 : count[q];
+  const int base0 = base;
   for (int64_t c0 = 0; c0 < ncols; c0 += 64) {
     const int64_t c = c0 + lane;
     const bool pred = c < ncols && S[q * ld + c] >= thr;
@@ -106,8 +109,8 @@ __global__ __launch_bounds__(256) void filter_collect_kernel(const float* __rest
   }
   if (lane == 0) {
     count[q] = base;
-    atomicAdd(&stats[2], (unsigned long long)base);
-    if (base > cap) atomicAdd(&stats[1], 1ull);
+    atomicAdd(&stats[2], (unsigned long long)(base - base0));
+    if (base > cap && base0 <= cap) atomicAdd(&stats[1], 1ull);   // counted once per query
   }
 }
 
@@ -230,8 +233,6 @@ __global__ void filter_scatter_lists_kernel(const int64_t* __restrict__ idx_src,
   }
 }
 
-int launch_cosine_f32(pvs_ctx* ctx, const float* A, int64_t M, const float* B, int64_t N, int64_t L, const float* inva,
-                      const float* invb, float* out, int64_t ldo);
 
 int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L,
                                 const float* invq, const float* invdb, int k, int64_t col_offset, int64_t* d_idx, float* d_val,
@@ -244,19 +245,25 @@ int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const 
   if (L > 65536) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: rows longer than 65536 take the exact path");
   if (L % 8 != 0 || L < 8 || reinterpret_cast<uintptr_t>(Q) % 16 || reinterpret_cast<uintptr_t>(DB) % 16)
     PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k needs 16-B aligned rows with L %% 8 == 0");
-  if (k < 1 || k > 128 || N > 32768) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: k <= 128 and at most 32768 database rows per call");
+  if (k < 1 || k > 128) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: k <= 128");
+  const int64_t NC = std::min<int64_t>(N, 32768);       // database rows per score panel
+  const bool multi = N > NC;
   const bool same = (Q == DB) && (nq == N) && (invq == invdb);
-  const int cap_lists = (4 * k + 64 + k - 1) / k;   // candidate slots: a multiple of k, >= 4k + 64
+  const bool square = same && !multi && (int64_t)nq * N <= ((int64_t)1 << 28);   // one symmetric launch covers everything
+  // candidate slots: a multiple of k; over several database panels the running threshold admits more columns early on
+  const int cap_lists = ((multi ? 16 : 4) * k + (multi ? 128 : 64) + k - 1) / k;
   const int cap = cap_lists * k;
-  const int64_t QT = same ? nq : std::min<int64_t>(nq, std::max<int64_t>(256, ((int64_t)1 << 28) / N));
-  if (same && (int64_t)nq * N > ((int64_t)1 << 28)) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: self-similarity panel too large");
+  const int64_t QT = square ? nq : std::min<int64_t>(nq, std::max<int64_t>(256, ((int64_t)1 << 28) / NC));
   const double eps = filter_eps(L);
   const float margin = (float)(2.0 * eps);
 
   // ---- workspace
   const size_t q16_b = ((size_t)nq * L * 2 + 255) / 256 * 256, db16_b = same ? 0 : ((size_t)N * L * 2 + 255) / 256 * 256;
   char* w5 = nullptr;
-  PVS_TRY(ws_reserve(ctx, 5, q16_b + db16_b, reinterpret_cast<void**>(&w5)));
+  if (ws_reserve(ctx, 5, q16_b + db16_b, reinterpret_cast<void**>(&w5)) != PVS_OK) {
+    (void)hipGetLastError();   // no room for the fp16 copies: the plain exact path needs none
+    PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: no device memory for the fp16 copies (%zu bytes)", q16_b + db16_b);
+  }
   _Float16* q16 = reinterpret_cast<_Float16*>(w5);
   _Float16* db16 = same ? q16 : reinterpret_cast<_Float16*>(w5 + q16_b);
   auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -274,7 +281,7 @@ int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const 
   float* cval = reinterpret_cast<float*>(w6 + o_cval);
   int* cnt = reinterpret_cast<int*>(w6 + o_cnt);
   float* panel = nullptr;
-  PVS_TRY(ws_reserve(ctx, 2, (size_t)QT * N * sizeof(float), reinterpret_cast<void**>(&panel)));
+  PVS_TRY(ws_reserve(ctx, 2, (size_t)QT * NC * sizeof(float), reinterpret_cast<void**>(&panel)));
   PVS_HIP(hipMemsetAsync(stats, 0, 32, ctx->stream));
 
   // ---- 1. scaled fp16 rows
@@ -293,15 +300,17 @@ int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const 
   std::vector<int> h_cnt;
   for (int64_t q0 = 0; q0 < nq; q0 += QT) {
     const int64_t qn = std::min(QT, nq - q0);
-    // ---- 2. bounded-error approximate scores, 3. approximate k-th best
-    PVS_TRY(launch_cosine_f16_bounded(ctx, q16 + q0 * L, qn, db16, N, L, invq16 + q0, invd16, panel, N));
-    PVS_TRY(launch_topk(ctx, panel, qn, N, N, k, 0, 0, aidx, aval));
-    // ---- 4. candidates
+    PVS_TRY(ws_reserve(ctx, 2, (size_t)QT * NC * sizeof(float), reinterpret_cast<void**>(&panel)));   // (the exact fallback shares the slot)
     PVS_HIP(hipMemsetAsync(cidx, 0xff, (size_t)qn * cap * 8, ctx->stream));
-    {
+    for (int64_t c0 = 0; c0 < N; c0 += NC) {
+      const int64_t cn = std::min(NC, N - c0);
+      // ---- 2. bounded-error approximate scores, 3. approximate k-th best (running over the database panels)
+      PVS_TRY(launch_cosine_f16_bounded(ctx, q16 + q0 * L, qn, db16 + c0 * L, cn, L, invq16 + q0, invd16 + c0, panel, cn));
+      PVS_TRY(launch_topk(ctx, panel, qn, cn, cn, k, c0, c0 > 0 ? 1 : 0, aidx, aval));
+      // ---- 4. candidates of this panel
       ScopedTimer tm(ctx, T_TOPK);
-      hipLaunchKernelGGL(filter_collect_kernel, dim3((unsigned)((qn + 3) / 4)), dim3(256), 0, ctx->stream, panel, qn, N, N, aidx, aval, k,
-                         margin, cap, (int64_t)0, cidx, cnt, stats);
+      hipLaunchKernelGGL(filter_collect_kernel, dim3((unsigned)((qn + 3) / 4)), dim3(256), 0, ctx->stream, panel, qn, cn, cn, aidx, aval, k,
+                         margin, cap, c0, c0 == 0 ? 1 : 0, cidx, cnt, stats);
     }
     // ---- 5. exact scores of the candidates
     {
@@ -322,22 +331,25 @@ int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const 
       for (int64_t i = 0; i < qn; ++i)
         if (h_cnt[(size_t)i] > cap) rows.push_back(i);
       const int64_t nr = (int64_t)rows.size();
+      const int64_t rb = std::max<int64_t>(1, std::min<int64_t>(nr, ((int64_t)1 << 28) / N));   // rows per exact batch (score rows <= 1 GiB)
       char* w4 = nullptr;
-      const size_t rows_b = al((size_t)nr * 8), g_b = al((size_t)nr * L * 4), gi_b = al((size_t)nr * 4), li_b = al((size_t)nr * k * 8);
-      PVS_TRY(ws_reserve(ctx, 3, rows_b + g_b + gi_b + li_b + al((size_t)nr * k * 4) + (size_t)nr * N * 4, reinterpret_cast<void**>(&w4)));
+      const size_t rows_b = al((size_t)nr * 8), g_b = al((size_t)rb * L * 4), gi_b = al((size_t)rb * 4), li_b = al((size_t)rb * k * 8);
+      PVS_TRY(ws_reserve(ctx, 3, rows_b + g_b + gi_b + li_b + al((size_t)rb * k * 4), reinterpret_cast<void**>(&w4)));
       int64_t* d_rows = reinterpret_cast<int64_t*>(w4);
       float* gq = reinterpret_cast<float*>(w4 + rows_b);
       float* gi = reinterpret_cast<float*>(w4 + rows_b + g_b);
       int64_t* li = reinterpret_cast<int64_t*>(w4 + rows_b + g_b + gi_b);
       float* lv = reinterpret_cast<float*>(w4 + rows_b + g_b + gi_b + li_b);
-      float* xpanel = reinterpret_cast<float*>(w4 + rows_b + g_b + gi_b + li_b + al((size_t)nr * k * 4));
       PVS_HIP(hipMemcpyAsync(d_rows, rows.data(), (size_t)nr * 8, hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(filter_gather_rows_kernel, dim3((unsigned)nr), dim3(256), 0, ctx->stream, Q + q0 * L, d_rows, L, gq,
-                         invq ? invq + q0 : nullptr, gi);
-      PVS_TRY(launch_cosine_f32(ctx, gq, nr, DB, N, L, gi, invdb, xpanel, N));
-      PVS_TRY(launch_topk(ctx, xpanel, nr, N, N, k, 0, 0, li, lv));
-      hipLaunchKernelGGL(filter_scatter_lists_kernel, dim3((unsigned)nr), dim3(64), 0, ctx->stream, li, lv, d_rows, k, d_idx + q0 * k,
-                         d_val + q0 * k);
+      for (int64_t r0 = 0; r0 < nr; r0 += rb) {
+        const int64_t rn = std::min(rb, nr - r0);
+        hipLaunchKernelGGL(filter_gather_rows_kernel, dim3((unsigned)rn), dim3(256), 0, ctx->stream, Q + q0 * L, d_rows + r0, L, gq,
+                           invq ? invq + q0 : nullptr, gi);
+        PVS_HIP(hipGetLastError());
+        PVS_TRY(cosine_topk_exact(ctx, gq, rn, DB, N, L, gi, invdb, k, li, lv));   // panel + select over all database rows
+        hipLaunchKernelGGL(filter_scatter_lists_kernel, dim3((unsigned)rn), dim3(64), 0, ctx->stream, li, lv, d_rows + r0, k,
+                           d_idx + q0 * k, d_val + q0 * k);
+      }
       PVS_HIP(hipGetLastError());
       PVS_HIP(hipStreamSynchronize(ctx->stream));   // `rows` is host memory going out of scope
       PVS_HIP(hipMemsetAsync(stats + 1, 0, 8, ctx->stream));
