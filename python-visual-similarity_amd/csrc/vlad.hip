@@ -621,7 +621,8 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
       }
       // members in descriptor order; the loads of up to PF rows are issued before the first of them is added (one load in
       // flight per lane group leaves the kernel latency-bound), the additions themselves stay strictly in order
-      constexpr int PF = NREG == 1 ? 8 : (NREG == 2 ? 4 : 2);
+      // (the fused-RootSIFT kinds do a row reduction + sqrt per member: deeper batching only adds register pressure there)
+      constexpr int PF = DescTraits<KIND>::rootsift ? 2 : (NREG == 1 ? 8 : (NREG == 2 ? 4 : 2));
       for (int p0 = s; p0 < e; p0 += PF) {
         float x[PF][NREG][VW];
 #pragma unroll
