@@ -505,6 +505,11 @@ def main():
                                                          inv_loc.data_ptr(), TOPK, idx.data_ptr(), val.data_ptr())
         elif world == 1:
             pd.retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, N, rank, world, TOPK, score_block, idx, val)
+        elif args.retrieval == "filtered":
+            # opt-in: this rank's queries against the gathered corpus through the prefilter + exact re-scoring (no list
+            # exchange needed; the first N gathered rows are the real ones, padding only follows the last block)
+            ctx.cosine_topk_filtered_dev(enc_loc.data_ptr(), n_loc, enc_all.data_ptr(), N, L, inv_loc.data_ptr(), inv_all.data_ptr(),
+                                         TOPK, idx.data_ptr(), val.data_ptr())
         else:
             # every block pair is scored once (dual-store GEMM), k-candidate lists exchanged, merged
             i_, v_ = pd.retrieve_symmetric(enc_all, inv_all, N, rank, world, TOPK, ops, a2a, new_tensor)
@@ -531,7 +536,7 @@ def main():
         ctx.timers_enable(False)
         return dt_, tm_
 
-    filtered = [args.retrieval == "filtered" and world == 1]
+    filtered = [args.retrieval == "filtered" and world == 1]   # (N > 1 reads args.retrieval directly in step())
     filt_stats = [None]
     other = None
     if world == 1:
@@ -600,7 +605,7 @@ def main():
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         **({"backend": "gloo REHEARSAL (ranks share GPUs, host-staged collectives): not a measurement"} if backend == "gloo" else {}),
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "retrieval": args.retrieval,
         "config": {"workload": f"configs[1]: {N} images x ragged SIFT-like descriptors (mean {total_desc / max(n_loc, 1):.0f}/image),"
                                f" D=128, VLAD K=256 encode + {N}x{N} cosine + top-{TOPK}",
                    "images": N, "descriptors_rank0": total_desc, "descriptor_rows": args.desc,
