@@ -96,6 +96,8 @@ def case_cosine_topk():
 def case_filtered():
     nq, N = int(rng.integers(1, 700)), int(rng.integers(2, 4000))
     L = int(rng.choice([8, 64, 1000, 1024, 2600, 4096, 8192]))
+    if rng.integers(0, 12) == 0:                # now and then a database of several score panels (running threshold)
+        N, L = int(rng.integers(33000, 90000)), int(rng.choice([8, 64, 256]))
     same = bool(rng.integers(0, 2))
     base = rng.standard_normal((N, L)).astype(np.float32) * float(rng.choice([1e-3, 1.0, 1e3]))
     if rng.integers(0, 2):
