@@ -186,7 +186,8 @@ static int launch_gemm_mfma(pvs_ctx* ctx, GemmArgs g, const GemmPlan& plan) {
 // shared front end of the two MFMA paths
 template <int MODEL>
 static int cosine_mfma(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int64_t N, int64_t L, const float* inva,
-                       const float* invb, float* out, int64_t ldo, float* out_t = nullptr, int64_t ldt = 0) {
+                       const float* invb, float* out, int64_t ldo, float* out_t = nullptr, int64_t ldt = 0, int64_t ld = 0,
+                       int accumulate = 0) {
   constexpr int BT = GemmModel<MODEL>::BM;
   const int tiles_m = (int)((M + BT - 1) / BT), tiles_n = (int)((N + BT - 1) / BT);
   if ((int64_t)tiles_m * tiles_n > 0x3fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "cosine: too many tiles for one launch");
@@ -195,7 +196,8 @@ static int cosine_mfma(pvs_ctx* ctx, const void* A, int64_t M, const void* B, in
   GemmPlan* plan = nullptr;
   PVS_TRY(build_plan(ctx, MODEL, tiles_m, tiles_n, symm, ctx->num_cu * GemmModel<MODEL>::PER_CU, &plan));
   GemmArgs g{};
-  g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = L; g.ldb = L; g.inva = inva; g.invb = invb;
+  g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = ld ? ld : L; g.ldb = ld ? ld : L; g.inva = inva; g.invb = invb;
+  g.accumulate = accumulate;
   g.out = out; g.ldo = ldo; g.out_t = out_t; g.ldt = ldt; g.tiles = plan->d_tiles; g.splitk = 1;
   PVS_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(const_cast<float**>(&g.zero16)), HIP_SYMBOL(g_zero16)));
   if (symm) return launch_gemm_mfma<true, MODEL>(ctx, g, *plan);
@@ -253,7 +255,15 @@ int launch_cosine_f16_bounded(pvs_ctx* ctx, const void* A, int64_t M, const void
   if (L <= 0 || L % 8 != 0 || reinterpret_cast<uintptr_t>(A) % 16 || reinterpret_cast<uintptr_t>(B) % 16)
     PVS_FAIL(PVS_ERR_UNSUPPORTED, "fp16 cosine needs 16-B aligned rows (L %% 8 == 0), got L = %lld", (long long)L);
   ScopedTimer tm(ctx, T_GEMM);
-  return cosine_mfma<2>(ctx, A, M, B, N, L, inva, invb, out, ldo);
+  // Rows longer than 32768 go through in segments accumulated in the output: over thousands of k-tiles the workgroups of an
+  // XCD drift apart, their panels stop sharing L2 and one long launch runs at a tenth of the rate (measured at L = 262,400).
+  constexpr int64_t SEG = 32768;
+  const char* a = static_cast<const char*>(A);
+  const char* b = static_cast<const char*>(B);
+  for (int64_t k0 = 0; k0 < L; k0 += SEG)
+    PVS_TRY(cosine_mfma<2>(ctx, a + k0 * 2, M, A == B ? a + k0 * 2 : b + k0 * 2, N, std::min(SEG, L - k0), inva, invb, out, ldo, nullptr, 0, L,
+                           k0 > 0 ? 1 : 0));
+  return PVS_OK;
 }
 
 // ------------------------------------------------------------------------------------- generic tiled fallback

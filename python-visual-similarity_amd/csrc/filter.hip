@@ -31,7 +31,9 @@ constexpr int FLT_SK = 32;     // k-values per chain slab staged in LDS
 constexpr int FLT_THREADS = FLT_PASS * 32;
 
 static double filter_eps(int64_t L) {
-  return 9.77e-4 * (1.0 + 1.0 / 4096.0) + (1088.0 + (double)L / 1024.0) * 1.1920929e-7 + 2.98e-8 * std::sqrt((double)L);
+  // (+ the roundings of the per-segment scaling and accumulation for rows longer than 32768)
+  return 9.77e-4 * (1.0 + 1.0 / 4096.0) + (1088.0 + (double)L / 1024.0 + 2.0 * (double)((L + 32767) / 32768)) * 1.1920929e-7 +
+         2.98e-8 * std::sqrt((double)L);
 }
 
 // ---- rows -> fp16, each row scaled by a power of two so that its largest magnitude lies in [2^14, 2^15)
@@ -240,9 +242,7 @@ int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const 
   // qualify: the exact re-scoring reproduces the f32 MFMA kernel, so the exact path must itself take that kernel
   if (col_offset != 0) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: col_offset must be 0");
   if (nq <= 0 || N <= 0) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: empty input");
-  // long rows (Fisher vectors, L = 262,400): the panels of the prefilter GEMM stop sharing L2 (the workgroups of an XCD drift
-  // apart over thousands of k-tiles) and it runs slower than the exact GEMM -- measured 174 vs 123 ms; not worth it there
-  if (L > 65536) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: rows longer than 65536 take the exact path");
+  if (L > (int64_t)8 * 1024 * 1024) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: rows too long");
   if (L % 8 != 0 || L < 8 || reinterpret_cast<uintptr_t>(Q) % 16 || reinterpret_cast<uintptr_t>(DB) % 16)
     PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k needs 16-B aligned rows with L %% 8 == 0");
   if (k < 1 || k > 128) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: k <= 128");

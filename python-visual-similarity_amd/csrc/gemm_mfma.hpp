@@ -64,6 +64,7 @@ struct GemmArgs {
   float* partial;         // [tiles in this launch][nparts][BM*BN] raw accumulators
   const float* zero16;    // 16 B of zeros in device memory (source for k-chunks past L)
   unsigned long long* stamps;  // diagnostic builds only (STAMP)
+  int accumulate;         // != 0: out += result (a long row dimension processed in segments, one launch each)
 };
 
 constexpr int GEMM_ROW_BYTES = 128;  // bytes of one operand row in a k-tile
@@ -446,7 +447,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
         const int64_t m = m0 + wm * (32 * MI) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float sa = (m < g.M && g.inva) ? g.inva[m] : 1.f;
         acc[a][b][r] = acc[a][b][r] * (sa * sb);  // sa*sb commutes: out[m][n] == out[n][m] bitwise
-        if (m < g.M && n < g.N) g.out[m * g.ldo + n] = acc[a][b][r];
+        if (m < g.M && n < g.N) {
+          if (g.accumulate) acc[a][b][r] += g.out[m * g.ldo + n];   // (the mirrored store below then carries the sum)
+          g.out[m * g.ldo + n] = acc[a][b][r];
+        }
       }
     }
   }

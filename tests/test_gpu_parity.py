@@ -658,7 +658,8 @@ def _topk_both(ctx, q, db, k, same):
 
 
 @pytest.mark.parametrize("case", ["vlad_self_k5", "vlad_self_k100", "queries_vs_db", "partial_chain", "ties_and_near_ties",
-                                  "overflow_to_exact", "not_qualified", "three_db_panels", "self_two_panels"])
+                                  "overflow_to_exact", "not_qualified", "three_db_panels", "self_two_panels", "long_rows_self",
+                                  "long_rows_queries"])
 def test_filtered_topk_is_bit_identical_to_the_exact_path(gpu_ctx, tables, case):
     """pvs_cosine_topk_filtered_dev must return exactly what pvs_cosine_topk_dev returns: indices and fp32 score bits."""
     rng = np.random.default_rng(hash(case) % 2**32)
@@ -691,6 +692,15 @@ def test_filtered_topk_is_bit_identical_to_the_exact_path(gpu_ctx, tables, case)
     elif case == "self_two_panels":          # self-similarity larger than one panel
         q = db = rng.standard_normal((40000, 64)).astype(np.float32)
         k = 5
+    elif case == "long_rows_self":           # L = 100,000: the prefilter GEMM runs in four accumulated segments
+        q = db = rng.standard_normal((700, 100000)).astype(np.float32)
+        q[5] = q[9]
+        k = 6
+    elif case == "long_rows_queries":
+        same = False
+        db = rng.standard_normal((900, 70000)).astype(np.float32)
+        q = (db[rng.integers(0, 900, 130)] + 0.8 * rng.standard_normal((130, 70000))).astype(np.float32)
+        k = 4
     elif case == "overflow_to_exact":        # every column within the margin of every other: more candidates than slots
         c = rng.standard_normal((1, 1024)).astype(np.float32)
         q = db = (c + 1e-3 * rng.standard_normal((600, 1024))).astype(np.float32)
