@@ -165,8 +165,8 @@ int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, i
 /* The same lists as pvs_cosine_topk_dev(col_offset 0, merge 0) -- bit-identical indices AND scores -- computed faster:
  * all pairs are scored with fp16 operands under a proven error bound, the columns within twice that bound of each query's
  * approximate k-th best are re-scored with the exact fp32 recurrence of the f32 GEMM kernel, and those are ranked.
- * Inputs that do not qualify (k > 128, rows not 16-B aligned or L % 8 != 0, non-finite values) silently take
- * the plain exact path.  h_stats (optional, int64[4]): [0] 1 if the filter ran, [1] queries redone by the exact path
+ * Inputs that do not qualify (k > 128, rows not 16-B aligned or L % 8 != 0, non-finite values, or scores so crowded that more
+ * than a tenth of the queries overflow their candidate slots) silently take the plain exact path.  h_stats (optional, int64[4]): [0] 1 if the filter ran, [1] queries redone by the exact path
  * (more candidates than slots), [2] candidates re-scored, [3] candidate slots per query. */
 int pvs_cosine_topk_filtered_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, const float* d_DB, int64_t N, int64_t L,
                                  const float* d_inv_q, const float* d_inv_db, int k, int64_t* d_idx, float* d_val,

@@ -312,6 +312,11 @@ int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const 
       hipLaunchKernelGGL(filter_collect_kernel, dim3((unsigned)((qn + 3) / 4)), dim3(256), 0, ctx->stream, panel, qn, cn, cn, aidx, aval, k,
                          margin, cap, c0, c0 == 0 ? 1 : 0, cidx, cnt, stats);
     }
+    // scores too crowded for the filter (more than a tenth of the queries have more candidates than slots, e.g. nearly
+    // orthogonal rows whose best scores sit inside the error margin of the bulk): the all-pairs path is the faster exact one
+    PVS_HIP(hipMemcpyAsync(hs, stats, 24, hipMemcpyDeviceToHost, ctx->stream));
+    PVS_HIP(hipStreamSynchronize(ctx->stream));
+    if (hs[1] * 10 > (unsigned long long)qn) PVS_FAIL(PVS_ERR_UNSUPPORTED, "filtered top-k: %llu of %lld queries exceed the candidate slots", hs[1], (long long)qn);
     // ---- 5. exact scores of the candidates
     {
       ScopedTimer tm(ctx, T_RESCORE);

@@ -711,14 +711,14 @@ def test_filtered_topk_is_bit_identical_to_the_exact_path(gpu_ctx, tables, case)
     (ei, ev, _), (fi, fv, st) = _topk_both(gpu_ctx, np.ascontiguousarray(q), np.ascontiguousarray(db), k, same)
     assert np.array_equal(ei, fi), (case, np.argwhere(ei != fi)[:5])
     assert np.array_equal(ev.view(np.uint32), fv.view(np.uint32)), (case, np.argwhere(ev != fv)[:5])
-    if case == "not_qualified":
-        assert not st["filtered"]
+    if case in ("not_qualified", "overflow_to_exact"):
+        assert not st["filtered"]            # (every query overflows its slots: the filter gives up, the exact path runs)
+    elif case == "self_two_panels":
+        pass                                 # 64-dim random rows: crowded scores, the filter may or may not give up
     else:
         assert st["filtered"] and st["candidates"] >= k * q.shape[0] - 3 * k
-        # the three all-zero rows score 0 against everything (all columns tie): they and the overflow case go to the exact path
-        want_redone = {"overflow_to_exact": q.shape[0], "ties_and_near_ties": 3}.get(case, 0)
-        if case != "self_two_panels":        # (64-dim random rows: many near ties, some queries legitimately overflow)
-            assert st["redone_exact"] == want_redone, st
+        # the three all-zero rows score 0 against everything (all columns tie): they are redone by the exact path
+        assert st["redone_exact"] == {"ties_and_near_ties": 3}.get(case, 0), st
 
 
 @pytest.mark.parametrize("kind", [DESC_F32, DESC_U8_ROOTSIFT])
