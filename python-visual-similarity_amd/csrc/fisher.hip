@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "desc_load.hpp"
+#include "reduce_kernels.hpp"
 
 namespace pvs {
 
@@ -905,35 +906,6 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
 }
 
 // ------------------------------------------------------------------------------------ training: one EM pass
-__global__ void em_chunk_offsets_kernel(int64_t* off, int64_t t0, int64_t tn, int chunk, int64_t nchunks) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= nchunks) off[i] = t0 + (i * chunk < tn ? i * chunk : tn);
-}
-
-// acc[j] (+)= part[0][j] + part[1][j] + ... in chunk order (fixed order: run-to-run identical)
-__global__ __launch_bounds__(256) void em_reduce_chunks_kernel(const double* __restrict__ part, int64_t nchunks, int64_t len,
-                                                               double* __restrict__ acc, int first) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= len) return;
-  double t = first ? 0.0 : acc[j];
-  for (int64_t c = 0; c < nchunks; ++c) t += part[c * len + j];
-  acc[j] = t;
-}
-
-// single block: acc (+)= sum of v[0..n) -- thread t takes t, t+256, ...; fixed tree afterwards
-__global__ __launch_bounds__(256) void em_sum_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ acc, int first) {
-  __shared__ double sh[256];
-  double t = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) t += v[i];
-  sh[threadIdx.x] = t;
-  __syncthreads();
-  for (int m = 128; m >= 1; m >>= 1) {
-    if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) acc[0] = (first ? 0.0 : acc[0]) + sh[0];
-}
-
 // E-step + sufficient statistics of one EM iteration (sklearn/mixture/_base.py:_e_step, _gaussian_mixture.py:
 // _estimate_gaussian_parameters): d_stats = [s0 (K) | per k: sum gamma x (D), sum gamma x**2 (D)] and
 // d_stats[K + 2KD] = sum_i log p(x_i).  The descriptors go through in batches of fixed-size chunks; every chunk's sums
@@ -965,16 +937,16 @@ int launch_gmm_em_step(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, i
     double* raw = reinterpret_cast<double*>(ws + tab_b + resp_b + lse_b + off_b);
     double* raw0 = reinterpret_cast<double*>(ws + tab_b + resp_b + lse_b + off_b + raw_b);
     PVS_TRY(posterior_mfma_on(ctx, g, x + t0 * ld, ld, tn, resp, tab, lse));
-    hipLaunchKernelGGL(em_chunk_offsets_kernel, dim3((unsigned)((nch + 256) / 256)), dim3(256), 0, ctx->stream, off, t0, tn, CHUNK, nch);
+    hipLaunchKernelGGL(chunk_offsets_kernel, dim3((unsigned)((nch + 256) / 256)), dim3(256), 0, ctx->stream, off, t0, tn, CHUNK, nch);
     {
       ScopedTimer tm(ctx, T_FMOM);
       MomMArgs m{x, D, ld, K, off, resp - t0 * K, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, 1.0, 2, 2.0,
                  nullptr, 1, nullptr, dblocks, raw, raw0};
       PVS_TRY((launch_moments<true, 2, 0, true>(ctx, dim3((unsigned)dblocks, (unsigned)nch), m)));
     }
-    hipLaunchKernelGGL(em_reduce_chunks_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, raw0, nch, (int64_t)K, d_stats, first);
-    hipLaunchKernelGGL(em_reduce_chunks_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, raw, nch, len, d_stats + K, first);
-    hipLaunchKernelGGL(em_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, lse, tn, d_stats + K + len, first);
+    hipLaunchKernelGGL(reduce_chunks_kernel<double>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, raw0, nch, (int64_t)K, d_stats, first);
+    hipLaunchKernelGGL(reduce_chunks_kernel<double>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, raw, nch, len, d_stats + K, first);
+    hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, ctx->stream, lse, tn, d_stats + K + len, first);
     PVS_HIP(hipGetLastError());
     first = 0;
   }

@@ -15,48 +15,11 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "reduce_kernels.hpp"
 
 namespace pvs {
 
 constexpr int LEARN_CHUNK = 4096;  // descriptors per pseudo-image of the aggregate pass (its LDS sort width)
-
-__global__ void learn_chunk_offsets_kernel(int64_t* off, int64_t t0, int64_t tn, int chunk, int64_t nchunks) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= nchunks) off[i] = t0 + (i * chunk < tn ? i * chunk : tn);
-}
-
-// acc[j] (+)= part[0][j] + part[1][j] + ...  in chunk order, fp64
-__global__ __launch_bounds__(256) void learn_reduce_f32_kernel(const float* __restrict__ part, int64_t nchunks, int64_t len,
-                                                               double* __restrict__ acc, int first) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= len) return;
-  double t = first ? 0.0 : acc[j];
-  for (int64_t c = 0; c < nchunks; ++c) t += (double)part[c * len + j];
-  acc[j] = t;
-}
-
-__global__ __launch_bounds__(256) void learn_reduce_f64_kernel(const double* __restrict__ part, int64_t nchunks, int64_t len,
-                                                               double* __restrict__ acc, int first) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= len) return;
-  double t = first ? 0.0 : acc[j];
-  for (int64_t c = 0; c < nchunks; ++c) t += part[c * len + j];
-  acc[j] = t;
-}
-
-// single block: acc[0] (+)= sum v[0..n)
-__global__ __launch_bounds__(256) void learn_sum_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ acc, int first) {
-  __shared__ double sh[256];
-  double t = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) t += v[i];
-  sh[threadIdx.x] = t;
-  __syncthreads();
-  for (int m = 128; m >= 1; m >>= 1) {
-    if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) acc[0] = (first ? 0.0 : acc[0]) + sh[0];
-}
 
 // member counts (integer atomics: order independent) and the number of labels that changed since the last pass
 __global__ __launch_bounds__(256) void learn_label_stats_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ prev,
@@ -141,10 +104,10 @@ int launch_kmeans_step(pvs_ctx* ctx, const pvs_codebook* cb, const float* x, int
     int64_t* off = reinterpret_cast<int64_t*>(ws);
     float* part = reinterpret_cast<float*>(ws + off_b);
     PVS_TRY(launch_assign(ctx, cb, x + t0 * D, PVS_DESC_F32, tn, D, d_labels + t0));
-    hipLaunchKernelGGL(learn_chunk_offsets_kernel, dim3((unsigned)((nch + 256) / 256)), dim3(256), 0, ctx->stream, off, t0, tn,
+    hipLaunchKernelGGL(chunk_offsets_kernel, dim3((unsigned)((nch + 256) / 256)), dim3(256), 0, ctx->stream, off, t0, tn,
                        LEARN_CHUNK, nch);
     PVS_TRY(launch_vlad_aggregate(ctx, cb, x, PVS_DESC_F32, D, off, nch, d_labels, prm, part, nullptr, /*raw=*/true));
-    hipLaunchKernelGGL(learn_reduce_f32_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, part, nch, len,
+    hipLaunchKernelGGL(reduce_chunks_kernel<float>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, part, nch, len,
                        d_stats, first);
     PVS_HIP(hipGetLastError());
     first = 0;
@@ -164,7 +127,7 @@ int launch_kmeans_step(pvs_ctx* ctx, const pvs_codebook* cb, const float* x, int
   hipLaunchKernelGGL(learn_counts_to_f64_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt + K, 1, d_stats + len + K + 1);
   hipLaunchKernelGGL(learn_sqdist_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, x, total, D, d_labels, cb->d_cent,
                      d_sqdist, bs);
-  hipLaunchKernelGGL(learn_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, bs, nblk, d_stats + len + K, 1);
+  hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, ctx->stream, bs, nblk, d_stats + len + K, 1);
   PVS_HIP(hipGetLastError());
   return PVS_OK;
 }
@@ -204,10 +167,10 @@ int launch_label_sums(pvs_ctx* ctx, const float* x, int64_t total, int D, const 
       hipLaunchKernelGGL(learn_square_kernel, dim3(4096), dim3(256), 0, ctx->stream, xb, tn * D, sq);
       xb = sq;
     }
-    hipLaunchKernelGGL(learn_chunk_offsets_kernel, dim3((unsigned)((nch + 256) / 256)), dim3(256), 0, ctx->stream, off, (int64_t)0, tn,
+    hipLaunchKernelGGL(chunk_offsets_kernel, dim3((unsigned)((nch + 256) / 256)), dim3(256), 0, ctx->stream, off, (int64_t)0, tn,
                        LEARN_CHUNK, nch);
     PVS_TRY(launch_vlad_aggregate(ctx, &cb, xb, PVS_DESC_F32, D, off, nch, d_labels + t0, prm, part, nullptr, /*raw=*/true));
-    hipLaunchKernelGGL(learn_reduce_f32_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, part, nch, len, d_out, first);
+    hipLaunchKernelGGL(reduce_chunks_kernel<float>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, part, nch, len, d_out, first);
     PVS_HIP(hipGetLastError());
     first = 0;
   }
@@ -292,8 +255,8 @@ int launch_gram(pvs_ctx* ctx, const float* x, int64_t total, int D, double* d_ou
     const int64_t rows = std::min<int64_t>(total - r0, nc * GRAM_ROWS);
     hipLaunchKernelGGL(learn_gram_kernel, dim3((unsigned)(ntile * ntile), (unsigned)nc), dim3(256), 0, ctx->stream, x + r0 * D, rows, D,
                        ntile, part, cs);
-    hipLaunchKernelGGL(learn_reduce_f64_kernel, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, ctx->stream, part, nc, tl, acc, first);
-    hipLaunchKernelGGL(learn_reduce_f64_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, cs, nc, (int64_t)D, d_out,
+    hipLaunchKernelGGL(reduce_chunks_kernel<double>, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, ctx->stream, part, nc, tl, acc, first);
+    hipLaunchKernelGGL(reduce_chunks_kernel<double>, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, cs, nc, (int64_t)D, d_out,
                        first);
     PVS_HIP(hipGetLastError());
     first = 0;
