@@ -198,9 +198,15 @@ int pvs_label_sums_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc
 /* h_out[D + D*D] = [sum_i x_i | sum_i x_i x_i^T] in fp64 (sklearn/decomposition/_pca.py covariance_eigh solver input). */
 int pvs_gram_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, double* h_out);
 /* k-means++ seeding (sklearn/cluster/_kmeans.py:_kmeans_plusplus): for n_cand <= 8 candidate centres (host, f32[n_cand][D])
- * d_dist[j][i] = |x_i - cand_j|^2 and h_pot[j] = sum_i min(d_mind[i], d_dist[j][i]) (d_mind NULL = +inf). */
-int pvs_seed_distances_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, const float* h_cand, int n_cand,
-                           const float* d_mind, float* d_dist, double* h_pot);
+ * d_dist[j][i] = |x_i - cand_j|^2 and h_pot[j] = sum_i min(d_mind[i], d_dist[j][i]) (d_mind NULL = +inf).  cand_on_device != 0:
+ * `cand` is a device pointer (e.g. pvs_seed_pick_dev's d_cand). */
+int pvs_seed_distances_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, const float* cand, int n_cand,
+                           const float* d_mind, float* d_dist, double* h_pot, int cand_on_device);
+/* The candidate draw of a seeding step on the device: candidate c is the first position of block h_blocks[c] (4096 entries of
+ * d_mind) where the running fp64 sum, started at h_base[c], reaches h_target[c] -- searchsorted(cumsum(d_mind), r) with the
+ * block chosen by the caller from pvs_min_update_dev's block sums.  Writes the rows to d_cand[c] and the indices to h_idx. */
+int pvs_seed_pick_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, const float* d_mind, const int64_t* h_blocks,
+                      const double* h_base, const double* h_target, int n_cand, float* d_cand, int64_t* h_idx);
 /* d_mind = min(d_mind, d_dist) (d_dist NULL = keep) and h_block_sums[ceil(n/4096)] = fp64 sums of d_mind per 4096 entries. */
 int pvs_min_update_dev(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total_desc, double* h_block_sums);
 

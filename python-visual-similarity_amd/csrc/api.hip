@@ -853,8 +853,9 @@ PVS_EXPORT int pvs_gram_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total
   return stats_to_host(ctx, d_out, n, h_out);
 }
 
-PVS_EXPORT int pvs_seed_distances_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, const float* h_cand, int n_cand,
-                                      const float* d_mind, float* d_dist, double* h_pot) {
+PVS_EXPORT int pvs_seed_distances_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, const float* cand, int n_cand,
+                                      const float* d_mind, float* d_dist, double* h_pot, int cand_on_device) {
+  const float* h_cand = cand;
   PVS_NEED(ctx, "ctx");
   PVS_NEED(d_x, "descriptors");
   PVS_NEED(h_cand, "candidates");
@@ -867,11 +868,41 @@ PVS_EXPORT int pvs_seed_distances_dev(pvs_ctx* ctx, const float* d_x, int D, int
   PVS_TRY(ws_reserve(ctx, 2, cand_b + 8 * sizeof(double), reinterpret_cast<void**>(&ws)));
   float* d_cand = reinterpret_cast<float*>(ws);
   double* d_pot = reinterpret_cast<double*>(ws + cand_b);
-  PVS_HIP(hipMemcpyAsync(d_cand, h_cand, (size_t)n_cand * D * 4, hipMemcpyHostToDevice, ctx->stream));
-  PVS_TRY(launch_seed_distances(ctx, d_x, total_desc, D, d_cand, n_cand, d_mind, d_dist, d_pot));
+  if (!cand_on_device) PVS_HIP(hipMemcpyAsync(d_cand, h_cand, (size_t)n_cand * D * 4, hipMemcpyHostToDevice, ctx->stream));
+  PVS_TRY(launch_seed_distances(ctx, d_x, total_desc, D, cand_on_device ? cand : d_cand, n_cand, d_mind, d_dist, d_pot));
   double pot8[8];
   PVS_TRY(stats_to_host(ctx, d_pot, 8, pot8));
   for (int j = 0; j < n_cand; ++j) h_pot[j] = pot8[j];
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_seed_pick_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, const float* d_mind, const int64_t* h_blocks,
+                                 const double* h_base, const double* h_target, int n_cand, float* d_cand, int64_t* h_idx) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(d_x, "descriptors");
+  PVS_NEED(d_mind, "mind");
+  PVS_NEED(h_blocks, "blocks");
+  PVS_NEED(h_base, "base");
+  PVS_NEED(h_target, "target");
+  PVS_NEED(d_cand, "candidates");
+  PVS_NEED(h_idx, "idx");
+  if (n_cand < 1 || n_cand > 64 || D <= 0 || total_desc <= 0) PVS_FAIL(PVS_ERR_INVALID, "1..64 candidates");
+  const int64_t nblk = (total_desc + 4095) / 4096;
+  for (int c = 0; c < n_cand; ++c)
+    if (h_blocks[c] < 0 || h_blocks[c] >= nblk) PVS_FAIL(PVS_ERR_INVALID, "candidate block out of range");
+  PVS_HIP(hipSetDevice(ctx->device));
+  char* ws = nullptr;
+  PVS_TRY(ws_reserve(ctx, 2, (size_t)n_cand * 32, reinterpret_cast<void**>(&ws)));
+  int64_t* d_blk = reinterpret_cast<int64_t*>(ws);
+  double* d_base = reinterpret_cast<double*>(ws + (size_t)n_cand * 8);
+  double* d_tgt = reinterpret_cast<double*>(ws + (size_t)n_cand * 16);
+  int64_t* d_idx = reinterpret_cast<int64_t*>(ws + (size_t)n_cand * 24);
+  PVS_HIP(hipMemcpyAsync(d_blk, h_blocks, (size_t)n_cand * 8, hipMemcpyHostToDevice, ctx->stream));
+  PVS_HIP(hipMemcpyAsync(d_base, h_base, (size_t)n_cand * 8, hipMemcpyHostToDevice, ctx->stream));
+  PVS_HIP(hipMemcpyAsync(d_tgt, h_target, (size_t)n_cand * 8, hipMemcpyHostToDevice, ctx->stream));
+  PVS_TRY(launch_seed_pick(ctx, d_x, total_desc, D, d_mind, d_blk, d_base, d_tgt, n_cand, d_idx, d_cand));
+  PVS_HIP(hipMemcpyAsync(h_idx, d_idx, (size_t)n_cand * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
   return PVS_OK;
 }
 

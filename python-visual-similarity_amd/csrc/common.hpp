@@ -168,6 +168,8 @@ int launch_label_sums(pvs_ctx* ctx, const float* x, int64_t total, int D, const 
 int launch_gram(pvs_ctx* ctx, const float* x, int64_t total, int D, double* d_out);
 int launch_seed_distances(pvs_ctx* ctx, const float* x, int64_t total, int D, const float* d_cand, int n_cand,
                           const float* d_mind, float* d_dist, double* d_pot);
+int launch_seed_pick(pvs_ctx* ctx, const float* x, int64_t total, int D, const float* d_mind, const int64_t* d_blk,
+                     const double* d_base, const double* d_target, int n_cand, int64_t* d_idx, float* d_cand);
 int launch_min_update(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total, double* d_block_sums);
 
 }  // namespace pvs

@@ -273,27 +273,44 @@ int launch_gram(pvs_ctx* ctx, const float* x, int64_t total, int D, double* d_ou
 // d_mind null = no centre chosen yet (potential = plain sum of distances).
 constexpr int SEED_MAX = 8;
 
-constexpr int SEED_ROWS = 1024;  // descriptors per block (16 rounds of 64)
+constexpr int SEED_ROWS = 1024;  // descriptors per block (32 rounds of 32)
 
+// Eight lanes share a descriptor (each takes dims 4 l, 4 l + 32, ... as float4: a row's lanes read 128 contiguous bytes per
+// step), every lane keeps its partial |x - cand_j|^2 for all candidates in registers, and one 3-step butterfly per candidate
+// folds the eight lanes -- 3 cross-lane steps per descriptor and candidate instead of 6 per wave-wide reduction.
 __global__ __launch_bounds__(256) void learn_seed_kernel(const float* __restrict__ X, int64_t total, int D, const float* __restrict__ cand,
                                                          int nc, const float* __restrict__ mind, float* __restrict__ dist,
                                                          double* __restrict__ block_pot /*[SEED_MAX][nblk]*/) {
-  extern __shared__ float sc[];  // [nc][D] candidates, then [64][SEED_MAX] row results
+  extern __shared__ float sc[];  // [nc][D] candidates, then [32][SEED_MAX] row results
   float* res = sc + nc * D;
   for (int i = threadIdx.x; i < nc * D; i += 256) sc[i] = cand[i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l8 = threadIdx.x & 7, grp = threadIdx.x >> 3;   // 32 descriptors per round
+  const bool vec = (D % 4 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0);
   double pot = 0.0;  // thread c < SEED_MAX: this block's potential for candidate c, rows in order
-  for (int round = 0; round < SEED_ROWS / 64; ++round) {
-    const int64_t r0 = (int64_t)blockIdx.x * SEED_ROWS + round * 64;
+  for (int round = 0; round < SEED_ROWS / 32; ++round) {
+    const int64_t r0 = (int64_t)blockIdx.x * SEED_ROWS + round * 32;
     if (r0 >= total) break;
-    for (int j = 0; j < 16; ++j) {
-      const int64_t row = r0 + wave * 16 + j;
-      float s[SEED_MAX];
+    const int64_t row = r0 + grp;
+    float s[SEED_MAX];
 #pragma unroll
-      for (int c = 0; c < SEED_MAX; ++c) s[c] = 0.f;
-      if (row < total) {
-        for (int d = lane; d < D; d += 64) {
+    for (int c = 0; c < SEED_MAX; ++c) s[c] = 0.f;
+    if (row < total) {
+      if (vec) {
+        for (int d = 4 * l8; d < D; d += 32) {
+          const float4 xv = *reinterpret_cast<const float4*>(X + row * D + d);
+#pragma unroll
+          for (int c = 0; c < SEED_MAX; ++c)
+            if (c < nc) {
+              const float4 cv = *reinterpret_cast<const float4*>(sc + c * D + d);
+              float t = xv.x - cv.x; s[c] = fmaf(t, t, s[c]);
+              t = xv.y - cv.y; s[c] = fmaf(t, t, s[c]);
+              t = xv.z - cv.z; s[c] = fmaf(t, t, s[c]);
+              t = xv.w - cv.w; s[c] = fmaf(t, t, s[c]);
+            }
+        }
+      } else {
+        for (int d = l8; d < D; d += 8) {
           const float xv = X[row * D + d];
 #pragma unroll
           for (int c = 0; c < SEED_MAX; ++c)
@@ -303,21 +320,24 @@ __global__ __launch_bounds__(256) void learn_seed_kernel(const float* __restrict
             }
         }
       }
+    }
 #pragma unroll
-      for (int c = 0; c < SEED_MAX; ++c)
-        for (int m = 32; m >= 1; m >>= 1) s[c] += __shfl_xor(s[c], m, 64);
-      if (lane == 0) {
-        const float md = (row < total && mind != nullptr) ? mind[row] : INFINITY;
+    for (int c = 0; c < SEED_MAX; ++c) {
+      s[c] += __shfl_xor(s[c], 1, 64);
+      s[c] += __shfl_xor(s[c], 2, 64);
+      s[c] += __shfl_xor(s[c], 4, 64);
+    }
+    if (l8 == 0) {
+      const float md = (row < total && mind != nullptr) ? mind[row] : INFINITY;
 #pragma unroll
-        for (int c = 0; c < SEED_MAX; ++c) {
-          if (c < nc && row < total) dist[(int64_t)c * total + row] = s[c];
-          res[(wave * 16 + j) * SEED_MAX + c] = (c < nc && row < total) ? fminf(md, s[c]) : 0.f;
-        }
+      for (int c = 0; c < SEED_MAX; ++c) {
+        if (c < nc && row < total) dist[(int64_t)c * total + row] = s[c];
+        res[grp * SEED_MAX + c] = (c < nc && row < total) ? fminf(md, s[c]) : 0.f;
       }
     }
     __syncthreads();
     if (threadIdx.x < SEED_MAX)
-      for (int j = 0; j < 64; ++j) pot += (double)res[j * SEED_MAX + threadIdx.x];
+      for (int jj = 0; jj < 32; ++jj) pot += (double)res[jj * SEED_MAX + threadIdx.x];
     __syncthreads();
   }
   if (threadIdx.x < SEED_MAX) block_pot[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = pot;
@@ -349,6 +369,56 @@ int launch_seed_distances(pvs_ctx* ctx, const float* x, int64_t total, int D, co
   PVS_TRY(ws_reserve(ctx, 1, (size_t)nblk * SEED_MAX * 8, reinterpret_cast<void**>(&bp)));
   hipLaunchKernelGGL(learn_seed_kernel, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, x, total, D, d_cand, n_cand, d_mind, d_dist, bp);
   hipLaunchKernelGGL(learn_seed_reduce_kernel, dim3(SEED_MAX), dim3(256), 0, ctx->stream, bp, nblk, d_pot);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+// Candidate draw of one seeding step, on the device: candidate c falls into block blk[c] (chosen by the host from the
+// per-block sums) at the first position whose running fp64 sum of d_mind, started at base[c], reaches target[c]
+// (= searchsorted(cumsum(mind), r), sklearn/cluster/_kmeans.py:_kmeans_plusplus); its row is copied to cand[c].
+__global__ __launch_bounds__(64) void learn_pick_kernel(const float* __restrict__ X, int64_t total, int D, const float* __restrict__ mind,
+                                                        const int64_t* __restrict__ blk, const double* __restrict__ base,
+                                                        const double* __restrict__ target, int64_t* __restrict__ out_idx,
+                                                        float* __restrict__ cand) {
+  __shared__ float vals[LEARN_CHUNK];
+  __shared__ double part[64];
+  __shared__ int64_t s_idx;
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int64_t lo = blk[c] * LEARN_CHUNK;
+  const int cnt = (int)min((int64_t)LEARN_CHUNK, total - lo);
+  for (int i = t; i < LEARN_CHUNK; i += 64) vals[i] = i < cnt ? mind[lo + i] : 0.f;   // coalesced; zeros past the end
+  __syncthreads();
+  // the block's running sum in a fixed order: 64 runs of 64 consecutive entries, then the runs in order
+  constexpr int RUN = LEARN_CHUNK / 64;
+  double p = 0.0;
+  for (int i = 0; i < RUN; ++i) p += (double)vals[t * RUN + i];
+  part[t] = p;
+  __syncthreads();
+  if (t == 0) {
+    double run = base[c];
+    int sub = 63;
+    for (int u = 0; u < 64; ++u) {
+      if (run + part[u] >= target[c]) { sub = u; break; }
+      run += part[u];
+    }
+    int pos = min(sub * RUN + RUN - 1, cnt - 1);
+    for (int i = 0; i < RUN; ++i) {
+      run += (double)vals[sub * RUN + i];
+      if (run >= target[c]) { pos = sub * RUN + i; break; }
+    }
+    pos = min(pos, cnt - 1);
+    s_idx = lo + pos;
+    out_idx[c] = lo + pos;
+  }
+  __syncthreads();
+  const int64_t row = s_idx;
+  for (int d = t; d < D; d += 64) cand[(int64_t)c * D + d] = X[row * D + d];
+}
+
+int launch_seed_pick(pvs_ctx* ctx, const float* x, int64_t total, int D, const float* d_mind, const int64_t* d_blk,
+                     const double* d_base, const double* d_target, int n_cand, int64_t* d_idx, float* d_cand) {
+  hipLaunchKernelGGL(learn_pick_kernel, dim3((unsigned)n_cand), dim3(64), 0, ctx->stream, x, total, D, d_mind, d_blk, d_base, d_target,
+                     d_idx, d_cand);
   PVS_HIP(hipGetLastError());
   return PVS_OK;
 }

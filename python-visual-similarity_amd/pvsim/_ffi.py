@@ -76,7 +76,8 @@ SIGNATURES = {
     "pvs_gmm_em_step_dev": [_vp, _vp, _vp, _i64, _vp],
     "pvs_label_sums_dev": [_vp, _vp, _int, _i64, _vp, _int, _int, _vp],
     "pvs_gram_dev": [_vp, _vp, _int, _i64, _vp],
-    "pvs_seed_distances_dev": [_vp, _vp, _int, _i64, _vp, _int, _vp, _vp, _vp],
+    "pvs_seed_distances_dev": [_vp, _vp, _int, _i64, _vp, _int, _vp, _vp, _vp, _int],
+    "pvs_seed_pick_dev": [_vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _int, _vp, _vp],
     "pvs_min_update_dev": [_vp, _vp, _vp, _i64, _vp],
     "pvs_timers_enable": [_vp, _int],
     "pvs_timers_reset": [_vp],

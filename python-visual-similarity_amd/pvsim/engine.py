@@ -353,12 +353,25 @@ class Context:
         check(_ffi.lib().pvs_label_sums_dev(self.handle, ptr(d_x), D, total_desc, ptr(d_labels), K, int(square), ptr(out)))
         return out
 
-    def seed_distances_dev(self, d_x, D, total_desc, cand, d_mind, d_dist):
-        cand = np.ascontiguousarray(cand, dtype=np.float32).reshape(-1, D)
-        pot = np.empty(cand.shape[0], dtype=np.float64)
-        check(_ffi.lib().pvs_seed_distances_dev(self.handle, ptr(d_x), D, total_desc, ptr(cand), cand.shape[0], ptr(d_mind),
-                                                ptr(d_dist), ptr(pot)))
+    def seed_distances_dev(self, d_x, D, total_desc, cand, d_mind, d_dist, n_cand=None):
+        """cand: host (n_cand, D) array, or a raw device pointer (int) together with n_cand"""
+        on_dev = not isinstance(cand, np.ndarray)
+        if not on_dev:
+            cand = np.ascontiguousarray(cand, dtype=np.float32).reshape(-1, D)
+            n_cand = cand.shape[0]
+        pot = np.empty(n_cand, dtype=np.float64)
+        check(_ffi.lib().pvs_seed_distances_dev(self.handle, ptr(d_x), D, total_desc, ptr(cand), n_cand, ptr(d_mind),
+                                                ptr(d_dist), ptr(pot), int(on_dev)))
         return pot
+
+    def seed_pick_dev(self, d_x, D, total_desc, d_mind, blocks, base, target, d_cand):
+        blocks = np.ascontiguousarray(blocks, dtype=np.int64)
+        base = np.ascontiguousarray(base, dtype=np.float64)
+        target = np.ascontiguousarray(target, dtype=np.float64)
+        idx = np.empty(len(blocks), dtype=np.int64)
+        check(_ffi.lib().pvs_seed_pick_dev(self.handle, ptr(d_x), D, total_desc, ptr(d_mind), ptr(blocks), ptr(base), ptr(target),
+                                           len(blocks), ptr(d_cand), ptr(idx)))
+        return idx
 
     def min_update_dev(self, d_mind, d_dist, total_desc):
         bs = np.empty((total_desc + 4095) // 4096, dtype=np.float64)

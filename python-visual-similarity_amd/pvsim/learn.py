@@ -128,59 +128,54 @@ def fit_pca(rows: DeviceRows, n_components: int) -> PCAModel:
 
 
 # ------------------------------------------------------------------------------------------------ k-means
-def _sample_by_mass(rows: DeviceRows, mind, block_sums: np.ndarray, r: np.ndarray) -> np.ndarray:
-    """searchsorted(cumsum(mind), r) without bringing mind to the host: the block from the per-4096 sums, then the
-    position inside that block (sklearn/cluster/_kmeans.py:_kmeans_plusplus, `candidate_ids`)."""
+def _draw_candidates(rows: DeviceRows, mind, block_sums: np.ndarray, r: np.ndarray, d_cand) -> np.ndarray:
+    """searchsorted(cumsum(mind), r) (sklearn/cluster/_kmeans.py:_kmeans_plusplus, `candidate_ids`) without bringing mind to
+    the host: the 4096-entry block of every draw from the per-block sums here, the position inside the block and the copy
+    of the drawn rows into d_cand on the device (pvs_seed_pick_dev) -- one round trip per seeding step."""
     cum = np.cumsum(block_sums)
-    out = np.empty(len(r), dtype=np.int64)
-    for j, v in enumerate(r):
-        b = min(int(np.searchsorted(cum, v)), len(cum) - 1)
-        lo = b * 4096
-        cnt = min(4096, rows.n - lo)
-        vals = mind.download((cnt,), np.float32, offset=lo * 4).astype(np.float64)
-        inner = np.cumsum(vals) + (cum[b - 1] if b else 0.0)
-        out[j] = lo + min(int(np.searchsorted(inner, v)), cnt - 1)
-    return out
+    blocks = np.minimum(np.searchsorted(cum, r), len(cum) - 1).astype(np.int64)
+    base = np.where(blocks > 0, cum[np.maximum(blocks - 1, 0)], 0.0)
+    return rows.ctx.seed_pick_dev(rows.ptr, rows.D, rows.n, mind.ptr, blocks, base, r, d_cand.ptr)
 
 
 def kmeans_plusplus(rows: DeviceRows, n_clusters: int, random_state=None, n_local_trials=None):
     """Greedy k-means++ (sklearn/cluster/_kmeans.py:_kmeans_plusplus): first centre uniform, every further centre the
     best of 2 + log(K) candidates drawn with probability proportional to the squared distance to the nearest chosen
-    centre.  Distances and potentials are device passes.  -> (centers (K, D) f32, indices (K,))"""
+    centre.  Draws, distances and potentials are device passes.  -> (centers (K, D) f32, indices (K,))"""
     ctx, n, D = rows.ctx, rows.n, rows.D
     if n_clusters > n:
         raise ValueError(f"n_samples={n} should be >= n_clusters={n_clusters}.")
     rng = _rng(random_state)
     trials = n_local_trials or 2 + int(math.log(n_clusters))
-    centers = np.empty((n_clusters, D), dtype=np.float32)
     indices = np.full(n_clusters, -1, dtype=np.int64)
     mind = ctx.buffer(n * 4).fill_bytes(_BIG_F32_BYTE)
     dist = ctx.buffer(min(trials, 8) * n * 4)
+    cand = ctx.buffer(max(trials, 1) * D * 4)
     try:
         indices[0] = rng.randint(n)
-        centers[0] = rows.row(indices[0])
-        pot = float(ctx.seed_distances_dev(rows.ptr, D, n, centers[:1], None, dist.ptr)[0])
+        pot = float(ctx.seed_distances_dev(rows.ptr, D, n, rows.row(indices[0])[None], None, dist.ptr)[0])
         sums = ctx.min_update_dev(mind.ptr, dist.ptr, n)
         for c in range(1, n_clusters):
-            cand = _sample_by_mass(rows, mind, sums, rng.uniform(size=trials) * pot)
+            ids = _draw_candidates(rows, mind, sums, rng.uniform(size=trials) * pot, cand)
             best = None                                         # (potential, descriptor index, group start, slot)
             for g0 in range(0, trials, 8):                      # the device scores up to 8 candidates per pass
-                grp = cand[g0:g0 + 8]
-                pots = ctx.seed_distances_dev(rows.ptr, D, n, rows.rows(grp), mind.ptr, dist.ptr)
+                m = min(8, trials - g0)
+                pots = ctx.seed_distances_dev(rows.ptr, D, n, cand.ptr + g0 * D * 4, mind.ptr, dist.ptr, n_cand=m)
                 j = int(np.argmin(pots))
                 if best is None or pots[j] < best[0]:
-                    best = (float(pots[j]), int(grp[j]), g0, j)
+                    best = (float(pots[j]), int(ids[g0 + j]), g0, j)
             best_pot, best_id, g_best, best_slot = best
             if g_best != ((trials - 1) // 8) * 8:               # the winner's distances were overwritten: recompute them
-                ctx.seed_distances_dev(rows.ptr, D, n, rows.rows([best_id]), mind.ptr, dist.ptr)
+                ctx.seed_distances_dev(rows.ptr, D, n, cand.ptr + (g_best + best_slot) * D * 4, mind.ptr, dist.ptr, n_cand=1)
                 best_slot = 0
             sums = ctx.min_update_dev(mind.ptr, dist.ptr + best_slot * n * 4, n)
             pot = best_pot
             indices[c] = best_id
-            centers[c] = rows.row(best_id)
+        centers = rows.rows(indices)
     finally:
         mind.free()
         dist.free()
+        cand.free()
     return centers, indices
 
 
