@@ -127,7 +127,38 @@ def case_filtered():
     assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32)), ("filtered val", nq, N, L, k, same)
 
 
-cases = [case_vlad, case_fisher, case_cosine_topk, case_filtered]
+def case_learn():
+    from pvsim import learn
+    import warnings
+    K = int(rng.choice([2, 5, 16, 40, 64]))
+    D = int(rng.choice([2, 8, 30, 64, 128]))
+    n = int(rng.choice([300, 5000, 20000]))
+    mu = rng.normal(0, 3, (K, D))
+    x = (mu[rng.integers(0, K, n)] + rng.standard_normal((n, D))).astype(np.float32)
+    rows = learn.DeviceRows.from_host(ctx, x)
+    c0 = x[rng.choice(n, K, replace=False)].copy()
+    m = learn.fit_kmeans(rows, K, init=c0, n_init=1, max_iter=3, tol=0.0)
+    rc, rl, _, _ = orc.kmeans_lloyd(x, c0, max_iter=3, tol=0.0)
+    assert np.mean(m.labels_ != rl) < 5e-3, ("kmeans labels", K, D, n, float(np.mean(m.labels_ != rl)))
+    if np.array_equal(m.labels_, rl):
+        assert np.allclose(m.cluster_centers_, rc, rtol=0, atol=2e-4 * (1 + np.abs(rc).max())), ("kmeans centres", K, D, n)
+    Kg = min(K, 16)
+    w0 = np.full(Kg, 1.0 / Kg)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g = learn.fit_gmm(rows, Kg, weights_init=w0, means_init=c0[:Kg].astype(np.float64), precisions_init=np.ones((Kg, D)),
+                          max_iter=3, tol=0.0)
+    w, mu_, cov, lower, _, _ = orc.gmm_em(x, w0, c0[:Kg].astype(np.float64), np.ones((Kg, D)), max_iter=3, tol=0.0)
+    assert np.allclose(g.means_, mu_, rtol=1e-8, atol=1e-10) and np.allclose(g.covariances_, cov, rtol=1e-8, atol=1e-10), ("gmm", Kg, D, n)
+    assert abs(g.lower_bound_ - lower) < 1e-8 * (1 + abs(lower)), ("gmm lower bound", Kg, D, n, g.lower_bound_, lower)
+    if n >= 10 * D and D >= 2:
+        p = learn.fit_pca(rows, max(1, D // 2))
+        c64, _, ev = orc.pca_fit(x.astype(np.float64), max(1, D // 2))
+        assert np.allclose(p.explained_variance_, ev, rtol=1e-8), ("pca variance", D, n)
+    rows.free()
+
+
+cases = [case_vlad, case_fisher, case_cosine_topk, case_filtered, case_learn]
 i = 0
 while time.time() < t_end:
     fn = cases[i % len(cases)]
