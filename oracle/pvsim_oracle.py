@@ -278,14 +278,16 @@ def pca_fit(x: np.ndarray, n_components: int):
     return vt[:n_components].copy(), mean, vals[:n_components].copy()
 
 
-def kmeans_lloyd(x: np.ndarray, init: np.ndarray, max_iter: int = 300, tol: float = 1e-4):
+def kmeans_lloyd(x: np.ndarray, init: np.ndarray, max_iter: int = 300, tol: float = 1e-4, center: bool = True):
     """sklearn/cluster/_kmeans.py:KMeans.fit (init given as an array, n_init=1) -> _kmeans_single_lloyd, fp32:
     X and the start are centred by X.mean(0); tol is scaled by mean(var(X, 0)); each iteration labels with the old
     centres (a3), moves every centre to its members' mean, relocates empty clusters to the farthest points
     (_k_means_common.pyx:_relocate_empty_clusters_dense); stops when the labels repeat or sum |shift|^2 <= tol; reruns
     the labelling unless the labels repeated; inertia = sum |x - c_label|^2.  -> (centres, labels, inertia, n_iter)"""
     x = np.array(x, dtype=np.float32)
-    mean = x.mean(axis=0)
+    # center=False: the same procedure in the caller's coordinates (what the device does; scikit-learn centres only to lose
+    # fewer fp32 digits, and a descriptor that sits between two centres may then fall on the other side)
+    mean = x.mean(axis=0) if center else np.zeros(x.shape[1], np.float32)
     x -= mean
     c = np.array(init, dtype=np.float32) - mean
     k = c.shape[0]
