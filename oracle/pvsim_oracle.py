@@ -310,7 +310,9 @@ def kmeans_lloyd(x: np.ndarray, init: np.ndarray, max_iter: int = 300, tol: floa
                 sums[new_id] = x[idx]
                 cnt[new_id] = 1
                 cnt[old] -= 1
-        new = sums / cnt[:, None]
+        # _k_means_common.pyx:_average_centers: a cluster left without weight keeps its old centre
+        with np.errstate(divide="ignore", invalid="ignore"):
+            new = np.where(cnt[:, None] > 0, sums / cnt[:, None], c).astype(np.float32)
         shift = float(((new - c) ** 2).sum())
         c = new
         if np.array_equal(labels, labels_old):

@@ -151,6 +151,13 @@ def case_learn():
         ref_l0 = orc.kmeans_predict(x, c0)
         xc = x - x.mean(axis=0)
         ref_l0c = orc.kmeans_predict(xc, c0 - x.mean(axis=0))
+        for it_ in (2, 3):
+            mi = learn.fit_kmeans(rows, K, init=c0, n_init=1, max_iter=it_, tol=0.0)
+            ri = orc.kmeans_lloyd(x, c0, max_iter=it_, tol=0.0, center=False)
+            print("DIAG iters", it_, "mismatches", int((mi.labels_ != ri[1]).sum()), "n_iter device/restatement", mi.n_iter_, ri[3],
+                  "nan in device centres", bool(np.isnan(mi.cluster_centers_).any()), "nan in restatement centres", bool(np.isnan(ri[0]).any()),
+                  "empty clusters device/restatement", int((np.bincount(mi.labels_, minlength=K) == 0).sum()),
+                  int((np.bincount(ri[1], minlength=K) == 0).sum()), flush=True)
         print("DIAG step0: device labels == plain restatement", np.array_equal(l0, ref_l0), "== centred restatement", np.array_equal(l0, ref_l0c),
               "counts", counts, "restatement counts (centred)", np.bincount(ref_l0c, minlength=K), flush=True)
         print("DIAG labels: mismatches", len(bad), "margins of the mismatched points under the restatement's centres", gap[bad][:8],
