@@ -269,7 +269,10 @@ PVS_EXPORT int pvs_gmm_create(pvs_ctx* ctx, const double* weights, const double*
   std::vector<double> prec((size_t)K * D), mup((size_t)K * D), cst(K), inv_mu((size_t)K * D), inv_sg((size_t)K * D);
   // descriptors are fp32: sklearn casts log(2 pi) to X's dtype (_gaussian_mixture.py:512); it cancels in predict_proba
   // but not in the EM lower bound
-  const double log2pi = (double)(float)std::log(2.0 * M_PI);
+  // and forms n_features * log(2 pi) in that dtype: a float32 product, rounded once (exact when D is a power of two)
+  const float l2pf = (float)std::log(2.0 * M_PI);
+  const volatile float dl2pf = (float)D * l2pf;
+  const double d_log2pi = (double)dl2pf;
   for (int k = 0; k < K; ++k) {
     double s = 0.0, ld = 0.0;
     for (int d = 0; d < D; ++d) {
@@ -284,7 +287,7 @@ PVS_EXPORT int pvs_gmm_create(pvs_ctx* ctx, const double* weights, const double*
       inv_mu[i] = 1.0 / (sw * std::sqrt(covariances[i]));
       inv_sg[i] = 1.0 / ((std::sqrt(2.0) * sw) * covariances[i]);
     }
-    cst[k] = -0.5 * (D * log2pi + s) + ld + std::log(weights[k]);
+    cst[k] = -0.5 * (d_log2pi + s) + ld + std::log(weights[k]);
   }
   int st = upload(ctx, &g->d_w, weights, (size_t)K);
   if (st == PVS_OK) st = upload(ctx, &g->d_mu, means, (size_t)K * D);

@@ -140,6 +140,7 @@ struct PostArgs {
   const double* precT;  // [D][K]
   const double* cst;    // [K]
   double* resp;         // [total][K]
+  double* lse;          // [total] or null (training)
 };
 
 __global__ __launch_bounds__(256) void gmm_posterior_kernel(PostArgs a) {
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256) void gmm_posterior_kernel(PostArgs a) {
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
     const double lse = mx + log(s);
     for (int k = lane; k < a.K; k += 64) a.resp[(r0 + r) * a.K + k] = exp(lp[r * a.K + k] - lse);
+    if (a.lse != nullptr && lane == 0) a.lse[r0 + r] = lse;
   }
 }
 
@@ -211,7 +213,7 @@ __global__ void transpose_tables_kernel(const double* __restrict__ prec, const d
 }
 
 static int posterior_on(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, int64_t total, double* d_resp,
-                        double* tabT) {
+                        double* tabT, double* d_lse = nullptr) {
   if (g->K > POST_KMAX) PVS_FAIL(PVS_ERR_UNSUPPORTED, "GMM with K = %d components exceeds the kernel limit (%d)", g->K,
                                 POST_KMAX);
   const int64_t kd = (int64_t)g->K * g->D;
@@ -219,7 +221,7 @@ static int posterior_on(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
   double* mupT = tabT + kd;
   hipLaunchKernelGGL(transpose_tables_kernel, dim3((unsigned)((kd + 255) / 256)), dim3(256), 0, ctx->stream, g->d_prec,
                      g->d_mup, g->K, g->D, precT, mupT);
-  PostArgs a{x, total, g->D, ld, g->K, mupT, precT, g->d_const, d_resp};
+  PostArgs a{x, total, g->D, ld, g->K, mupT, precT, g->d_const, d_resp, d_lse};
   const size_t lds = (size_t)POST_DK * POST_ROWS * sizeof(double2) + (size_t)POST_ROWS * g->K * sizeof(double);
   PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_posterior_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -418,6 +420,7 @@ struct MomMArgs {
   int dblocks;
   double* raw_s;        // RAW: [n_images][K][2D]  sum_i gamma x | sum_i gamma x**2
   double* raw_s0;       // RAW: [n_images][K]      sum_i gamma
+  int resp_ld, k0;      // gamma row stride and first cluster of this launch (RAW over a mixture of more than 256 components)
 };
 
 __device__ __forceinline__ double power_norm64(double v, double p);
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int ii = gi + 2 * q;
-      gv[q] = (i0 + ii < n && gk < K) ? a.resp[(row0 + i0 + ii) * K + gk] : 0.0;
+      gv[q] = (i0 + ii < n && gk < K) ? a.resp[(row0 + i0 + ii) * a.resp_ld + a.k0 + gk] : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -870,7 +873,7 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
   ScopedTimer tm(ctx, T_FMOM);
   if (mfma) {
     MomMArgs m{x, D, ld, K, d_offsets + img0, resp_abs, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, prm.power_norm_weight, norm_mode, ord,
-               out_b, out_f64, partial, dblocks, nullptr, nullptr};
+               out_b, out_f64, partial, dblocks, nullptr, nullptr, K, 0};
     const int pm = prm.power_norm_weight == 1.0 ? 0 : (prm.power_norm_weight == 0.5 ? 1 : 2);
     const int nm = norm_mode == 2 ? 2 : (norm_mode == 0 ? 0 : 1);
     const dim3 grid((unsigned)dblocks, (unsigned)n_img);
@@ -912,9 +915,10 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
 // are formed by the Fisher moments kernel (RAW) and the chunks are added in order, in fp64.
 int launch_gmm_em_step(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, int64_t total, double* d_stats) {
   const int K = g->K, D = g->D;
-  if (K > PM_COLS) PVS_FAIL(PVS_ERR_UNSUPPORTED, "GMM training on the device supports at most %d components (got %d)", PM_COLS, K);
+  if (K > POST_KMAX) PVS_FAIL(PVS_ERR_UNSUPPORTED, "GMM training on the device supports at most %d components (got %d)", POST_KMAX, K);
   if (total <= 0) PVS_FAIL(PVS_ERR_INVALID, "GMM training needs at least one descriptor");
   constexpr int CHUNK = 2048;
+  const int nslab = (K + PM_COLS - 1) / PM_COLS;   // the moments kernel takes 256 components at a time
   const int64_t len = (int64_t)K * 2 * D;
   const size_t tab_b = ((size_t)2 * K * D * 8 + 255) / 256 * 256;
   const int64_t rows_per_batch = std::max<int64_t>(CHUNK, (((int64_t)2 << 30) / ((int64_t)K * 8)) / CHUNK * CHUNK);
@@ -926,8 +930,9 @@ int launch_gmm_em_step(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, i
     const size_t resp_b = ((size_t)tn * K * 8 + 255) / 256 * 256;
     const size_t lse_b = ((size_t)tn * 8 + 255) / 256 * 256;
     const size_t off_b = ((size_t)(nch + 1) * 8 + 255) / 256 * 256;
-    const size_t raw_b = ((size_t)nch * len * 8 + 255) / 256 * 256;
-    const size_t s0_b = ((size_t)nch * K * 8 + 255) / 256 * 256;
+    const int64_t slab_len = (int64_t)PM_COLS * 2 * D;
+    const size_t raw_b = ((size_t)nch * slab_len * 8 + 255) / 256 * 256;
+    const size_t s0_b = ((size_t)nch * PM_COLS * 8 + 255) / 256 * 256;
     char* ws = nullptr;
     PVS_TRY(ws_reserve(ctx, 1, tab_b + resp_b + lse_b + off_b + raw_b + s0_b, reinterpret_cast<void**>(&ws)));
     double* tab = reinterpret_cast<double*>(ws);
@@ -936,16 +941,23 @@ int launch_gmm_em_step(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, i
     int64_t* off = reinterpret_cast<int64_t*>(ws + tab_b + resp_b + lse_b);
     double* raw = reinterpret_cast<double*>(ws + tab_b + resp_b + lse_b + off_b);
     double* raw0 = reinterpret_cast<double*>(ws + tab_b + resp_b + lse_b + off_b + raw_b);
-    PVS_TRY(posterior_mfma_on(ctx, g, x + t0 * ld, ld, tn, resp, tab, lse));
+    if (K <= PM_COLS) PVS_TRY(posterior_mfma_on(ctx, g, x + t0 * ld, ld, tn, resp, tab, lse));
+    else PVS_TRY(posterior_on(ctx, g, x + t0 * ld, ld, tn, resp, tab, lse));
     hipLaunchKernelGGL(chunk_offsets_kernel, dim3((unsigned)((nch + 256) / 256)), dim3(256), 0, ctx->stream, off, t0, tn, CHUNK, nch);
-    {
-      ScopedTimer tm(ctx, T_FMOM);
-      MomMArgs m{x, D, ld, K, off, resp - t0 * K, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, 1.0, 2, 2.0,
-                 nullptr, 1, nullptr, dblocks, raw, raw0};
-      PVS_TRY((launch_moments<true, 2, 0, true>(ctx, dim3((unsigned)dblocks, (unsigned)nch), m)));
+    for (int sl = 0; sl < nslab; ++sl) {
+      const int k0 = sl * PM_COLS, ks = std::min(PM_COLS, K - k0);
+      {
+        ScopedTimer tm(ctx, T_FMOM);
+        MomMArgs m{x, D, ld, ks, off, resp - t0 * K, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, 1.0, 2, 2.0,
+                   nullptr, 1, nullptr, dblocks, raw, raw0, K, k0};
+        PVS_TRY((launch_moments<true, 2, 0, true>(ctx, dim3((unsigned)dblocks, (unsigned)nch), m)));
+      }
+      const int64_t sl_len = (int64_t)ks * 2 * D;
+      hipLaunchKernelGGL(reduce_chunks_kernel<double>, dim3((unsigned)((ks + 255) / 256)), dim3(256), 0, ctx->stream, raw0, nch, (int64_t)ks,
+                         d_stats + k0, first);
+      hipLaunchKernelGGL(reduce_chunks_kernel<double>, dim3((unsigned)((sl_len + 255) / 256)), dim3(256), 0, ctx->stream, raw, nch, sl_len,
+                         d_stats + K + (int64_t)k0 * 2 * D, first);
     }
-    hipLaunchKernelGGL(reduce_chunks_kernel<double>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, raw0, nch, (int64_t)K, d_stats, first);
-    hipLaunchKernelGGL(reduce_chunks_kernel<double>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, raw, nch, len, d_stats + K, first);
     hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, ctx->stream, lse, tn, d_stats + K + len, first);
     PVS_HIP(hipGetLastError());
     first = 0;

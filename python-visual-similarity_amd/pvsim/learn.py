@@ -317,8 +317,8 @@ def fit_gmm(rows: DeviceRows, n_components: int, *, tol: float = 1e-3, reg_covar
     ctx, n, D, K = rows.ctx, rows.n, rows.D, int(n_components)
     if n < 2 or n < K:
         raise ValueError(f"Expected n_samples >= n_components but got n_components = {K}, n_samples = {n}")
-    if K > 256:
-        raise NotImplementedError("device GMM training supports at most 256 components")
+    if K > 1024:
+        raise NotImplementedError("device GMM training supports at most 1024 components")
     rng = _rng(random_state)
     best = None
     for _ in range(max(int(n_init), 1)):

@@ -912,3 +912,25 @@ def test_learn_from_raw_sift_descriptors(tables):
     ref_c, ref_l, _, _ = orc.kmeans_lloyd(x, c0, max_iter=4, tol=0.0)
     assert np.mean(ref_l != a.clustering_model.labels_) < 2e-3          # near ties may flip (fp32 sums in another order)
     np.testing.assert_allclose(a.clustering_model.cluster_centers_, ref_c, rtol=0, atol=2e-4)
+
+
+def test_learn_gmm_more_than_256_components(gpu_ctx):
+    """EM with K = 300: the posterior runs on the general kernel, the moments 256 components at a time; three iterations
+    against the NumPy restatement of scikit-learn's loop."""
+    import warnings
+    from pvsim import learn
+    rng = np.random.default_rng(12)
+    K, D, n = 300, 24, 30000
+    mu = rng.normal(0, 4, (K, D))
+    x = (mu[rng.integers(0, K, n)] + rng.standard_normal((n, D))).astype(np.float32)
+    rows = learn.DeviceRows.from_host(gpu_ctx, x)
+    w0, m0, p0 = np.full(K, 1.0 / K), mu + 0.3 * rng.standard_normal((K, D)), np.ones((K, D))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g = learn.fit_gmm(rows, K, weights_init=w0, means_init=m0, precisions_init=p0, max_iter=3, tol=0.0)
+    w, m, c, lower, _, _ = orc.gmm_em(x, w0, m0, 1.0 / p0, max_iter=3, tol=0.0)
+    np.testing.assert_allclose(g.weights_, w, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(g.means_, m, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(g.covariances_, c, rtol=1e-8, atol=1e-10)
+    assert abs(g.lower_bound_ - lower) < 1e-9
+    rows.free()
