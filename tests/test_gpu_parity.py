@@ -767,31 +767,6 @@ def test_prefiltered_assignment_odd_shapes(gpu_ctx, K, D, monkeypatch):
     assert np.array_equal(pre, orc.kmeans_predict(x, C)) or np.mean(pre != orc.kmeans_predict(x, C)) < 1e-3
 
 
-@pytest.mark.parametrize("ranks,exchange", [(2, "allgather"), (3, "neighbours"), (4, "neighbours")])
-def test_multi_rank_bench_rehearsal(ranks, exchange):
-    """bench.py's N > 1 path end to end with 2-4 ranks sharing this GPU (gloo, host-staged collectives): image sharding,
-    exchange, block-pair scoring, all-to-all of candidate lists, merge -- each rank asserts that its lists equal the
-    single-GPU ranking bit for bit.  Everything but the RCCL transport of the measured configuration."""
-    import json
-    import os
-    import socket
-    import subprocess
-    import sys
-    from conftest import REPO
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, PVS_BENCH_BACKEND="gloo", PVS_BENCH_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1",
-           "--images", "1030", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    assert r.stderr.count("identical to the single-GPU ranking") == ranks, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == ranks and "REHEARSAL" in line["backend"] and line["exchange"] == exchange
-
-
 @pytest.mark.parametrize("M,N,L", [(300, 300, 32768), (130, 257, 4096), (129, 700, 2600), (64, 64, 40)])
 def test_cosine_scores_are_the_defined_fp32_recurrence(gpu_ctx, M, N, L):
     """Beyond the 2e-6 tolerance against the reference's BLAS result: the exact GEMM's score is a defined recurrence
