@@ -30,6 +30,12 @@ def gpu_ctx():
     """One engine context on cuda:0 for the whole GPU session (fails loudly if the HIP
     library is missing or no device is present -- there is no CPU fallback)."""
     import pvsim
+    try:    # torch first: on the test boxes a process whose HIP runtime was opened by the engine before torch's own
+        import torch    # initialisation leaves torch without a GPU ("No HIP GPUs are available"); the other order works
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     ctx = pvsim.Context(0)
     yield ctx
     ctx.close()
