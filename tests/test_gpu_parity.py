@@ -910,3 +910,36 @@ def test_learn_gmm_more_than_256_components(gpu_ctx):
     np.testing.assert_allclose(g.covariances_, c, rtol=1e-8, atol=1e-10)
     assert abs(g.lower_bound_ - lower) < 1e-9
     rows.free()
+
+
+@pytest.mark.parametrize("nq,N,k", [(9, 8189, 5), (4, 300, 16), (3, 20000, 1), (6, 7, 10), (5, 40000, 8)])
+def test_small_k_kernel_equals_the_radix_select(gpu_ctx, nq, N, k, monkeypatch):
+    """k <= 16 takes the extraction kernel: same keys, same order as the radix select -- ties, NaN, -0.0, -inf, fewer columns
+    than k, several 8192-column chunks and the running-list merge included."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(nq * 1000 + N + k)
+    s = rng.standard_normal((nq, N)).astype(np.float32)
+    m = s[:, 1::7].shape[1]
+    s[:, 0:7 * m:7] = s[:, 1::7]                                # exact ties
+    s[0, :3] = np.nan
+    s[1, 2] = -0.0
+    s[1, 3] = 0.0
+    s[2, :] = -np.inf
+    panels = [(0, N // 2), (N // 2, N)] if N > 20 else [(0, N)]
+    out = []
+    for select_only in (True, False):
+        if select_only:
+            monkeypatch.setenv("PVS_TOPK_SELECT_ONLY", "1")
+        else:
+            monkeypatch.delenv("PVS_TOPK_SELECT_ONLY", raising=False)
+        idx = torch.full((nq, k), -9, dtype=torch.int64, device=dev)
+        val = torch.full((nq, k), -9.0, dtype=torch.float32, device=dev)
+        for p, (c0, c1) in enumerate(panels):                  # second panel merges into the running lists
+            t = torch.from_numpy(np.ascontiguousarray(s[:, c0:c1])).to(dev)
+            torch.cuda.synchronize()
+            gpu_ctx.topk_dev(t.data_ptr(), nq, c1 - c0, c1 - c0, k, c0, p > 0, idx.data_ptr(), val.data_ptr())
+            gpu_ctx.sync()
+        out.append((idx.cpu().numpy(), val.cpu().numpy()))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
