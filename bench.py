@@ -417,11 +417,16 @@ def main():
     # the collectives go through host copies.  It exercises the whole multi-rank code path except the RCCL transport; its
     # numbers mean nothing.  The measured configuration is always nccl (= RCCL), one rank per GPU.
     backend = os.environ.get("PVS_BENCH_BACKEND", "nccl")
+    # PVS_BENCH_FORCE_DIST=1 (started through torch.distributed.run with ONE rank): the multi-rank code path -- process group, one
+    # stream shared with RCCL, asynchronous exchange, block-pair retrieval, list all-to-all -- on a single GPU; a self-check of
+    # that path against the plain single-GPU retrieval, not a measurement
+    forced = os.environ.get("PVS_BENCH_FORCE_DIST") == "1" and world == 1
+    multi = world > 1 or forced
     if backend == "gloo":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "gloo":
             dist.init_process_group("gloo")
@@ -432,6 +437,7 @@ def main():
     # block-pair scheme reads -- (P-1)//2 full blocks plus, for even P, a full or half partner block -- by batched
     # point-to-point transfers instead of the all-gather (-44 % bytes at P = 8)
     exchange_mode = os.environ.get("PVS_BENCH_EXCHANGE", "allgather")
+    overlap = os.environ.get("PVS_BENCH_OVERLAP", "1") != "0"      # exchange overlapped with the (r, r) block (RCCL only)
 
     def coll(fn, out_t, in_t):
         """out_t <- collective(in_t); through host copies in the gloo rehearsal mode"""
@@ -444,7 +450,7 @@ def main():
 
     # N > 1: ONE stream for the engine, torch and (through torch's stream semantics) RCCL -- the step then needs no host
     # synchronisation between encode, exchange and retrieval, and the CPU can run ahead of the many small launches
-    one_stream = world > 1
+    one_stream = multi
     if one_stream:
         side = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(side)
@@ -471,7 +477,7 @@ def main():
     inv_loc = torch.ones((per,), dtype=torch.float32, device=dev)
     if n_loc < per:
         enc_loc[n_loc:].zero_()
-    if world > 1:
+    if multi:
         enc_all = torch.empty((world * per, L), dtype=torch.float32, device=dev)
         inv_all = torch.empty((world * per,), dtype=torch.float32, device=dev)
     else:
@@ -530,43 +536,70 @@ def main():
                     stage.append((dst, buf))
                     dst = buf
                 ops.append(dist.P2POp(dist.irecv, dst, peer))
-        if ops:
-            for w_ in dist.batch_isend_irecv(ops):
+        works = dist.batch_isend_irecv(ops) if ops else []
+        if backend == "gloo" or not overlap:
+            for w_ in works:
                 w_.wait()
-        for dst, buf in stage:
-            dst.copy_(buf)
+            for dst, buf in stage:
+                dst.copy_(buf)
+            return []
+        return [w_.wait for w_ in works]
+
+    def exchange_begin():
+        """Start the exchange of the encoded blocks; returns the waiters to call before another rank's rows are read.  With RCCL
+        the collectives are asynchronous (they run on the process group's own stream after this stream's encode, and a waiter
+        only makes THIS stream wait for them), so the (r, r) block is scored while the blocks travel.  The gloo rehearsal
+        stages through the host and is synchronous."""
+        sync_mode = backend == "gloo" or not overlap
+        if exchange_mode == "neighbours":
+            ws = exchange_neighbours()
+        elif sync_mode:
+            coll(dist.all_gather_into_tensor, enc_all, enc_loc)
+            ws = []
+        else:
+            ws = [dist.all_gather_into_tensor(enc_all, enc_loc, async_op=True).wait]
+        if sync_mode:
+            coll(dist.all_gather_into_tensor, inv_all, inv_loc)
+        else:
+            ws.append(dist.all_gather_into_tensor(inv_all, inv_loc, async_op=True).wait)
+        return ws
 
     def step():
         ctx.vlad_encode_dev(cb, desc.data_ptr(), kind, d_off.data_ptr(), n_loc, total_desc, enc_loc.data_ptr(),
                             d_inv_norm=inv_loc.data_ptr())
-        if world > 1:
+        waiters = []
+        if multi:
             if not one_stream:
                 ctx.sync()                               # encode (ctx stream) -> collective (torch stream)
-            if exchange_mode == "neighbours":
-                exchange_neighbours()
-            else:
-                coll(dist.all_gather_into_tensor, enc_all, enc_loc)
-            coll(dist.all_gather_into_tensor, inv_all, inv_loc)
+            waiters = exchange_begin()
+
+        def exchanged():
+            for w_ in waiters:
+                w_()
             if not one_stream:
                 torch.cuda.current_stream().synchronize()
-        if world == 1 and filtered[0]:
+
+        if not multi and filtered[0]:
             filt_stats[0] = ctx.cosine_topk_filtered_dev(enc_loc.data_ptr(), n_loc, enc_loc.data_ptr(), n_loc, L, inv_loc.data_ptr(),
                                                          inv_loc.data_ptr(), TOPK, idx.data_ptr(), val.data_ptr())
-        elif world == 1:
+        elif not multi:
             pd.retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, N, rank, world, TOPK, score_block, idx, val)
         elif args.retrieval == "filtered":
+            exchanged()
             # opt-in: this rank's queries against the gathered corpus through the prefilter + exact re-scoring (no list
             # exchange needed; the first N gathered rows are the real ones, padding only follows the last block)
             ctx.cosine_topk_filtered_dev(enc_loc.data_ptr(), n_loc, enc_all.data_ptr(), N, L, inv_loc.data_ptr(), inv_all.data_ptr(),
                                          TOPK, idx.data_ptr(), val.data_ptr())
         else:
             # every block pair is scored once (dual-store GEMM), k-candidate lists exchanged, merged
-            i_, v_ = pd.retrieve_symmetric(enc_all, inv_all, N, rank, world, TOPK, ops, a2a, new_tensor)
+            # the (r, r) block reads the local copy, so it runs while the other blocks are still arriving
+            i_, v_ = pd.retrieve_symmetric(enc_all, inv_all, N, rank, world, TOPK, ops, a2a, new_tensor,
+                                           own=(enc_loc, inv_loc), before_cross=exchanged)
             idx[:n_loc].copy_(i_)
             val[:n_loc].copy_(v_)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -585,17 +618,17 @@ def main():
         ctx.timers_enable(False)
         return dt_, tm_
 
-    filtered = [args.retrieval == "filtered" and world == 1]   # (N > 1 reads args.retrieval directly in step())
+    filtered = [args.retrieval == "filtered" and not multi]   # (N > 1 reads args.retrieval directly in step())
     filt_stats = [None]
     other = None
-    if world == 1:
+    if not multi:
         # the variant that is NOT the headline of this run is timed first, its lists kept for the bit-for-bit comparison
         filtered[0] = not filtered[0]
         o_dt, o_tm = timed_steps()
         other = {"dt": o_dt, "timers": o_tm, "idx": idx.clone(), "val": val.clone(), "was_filtered": filtered[0], "stats": filt_stats[0]}
         filtered[0] = not filtered[0]
     dt, timers = timed_steps()
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -605,7 +638,7 @@ def main():
     # ---- sanity inside the bench: self-retrieval must return the image itself first
     got = idx[:n_loc, 0].cpu().numpy()
     assert np.array_equal(got, np.arange(lo, hi)), "self-retrieval failed: top-1 is not the query image"
-    if world > 1 and backend == "gloo":
+    if multi and (backend == "gloo" or forced):
         # rehearsal: the block-pair scheme must give exactly what one GPU gives for this rank's queries
         ri = torch.empty((n_loc, TOPK), dtype=torch.int64, device=dev)
         rv = torch.empty((n_loc, TOPK), dtype=torch.float32, device=dev)
@@ -622,7 +655,7 @@ def main():
         print(f"[rehearsal] rank {rank}: {n_loc} queries identical to the single-GPU ranking", file=sys.stderr)
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -632,7 +665,7 @@ def main():
     # ~half of the algorithmic 2*N*M*L of SURVEY.md section 8(d); `achieved` counts executed flop only (never above peak).
     gemm_ms, gemm_n = timers["cosine_gemm"]
     t128 = (n_loc + 127) // 128
-    if world == 1:
+    if not multi:
         alg_flop = 2.0 * N * N * L
         flop_per_launch = 2.0 * 128 * 128 * L * (t128 * (t128 + 1) // 2)      # upper-triangle tiles
     else:
@@ -644,7 +677,7 @@ def main():
     achieved = flop_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
     # the exact f32 GEMM only (the same process also runs the fp16 prefilter GEMM of the filtered variant)
     traffic, traffic_src = pmc_traffic("pvs::gemm_mfma_kernel", keep=lambda nm: not _gemm_is_f16(nm))
-    if world != 1 or N != 8189 or filtered[0]:
+    if multi or N != 8189 or filtered[0]:
         traffic, traffic_src = None, None             # the committed counters are for the default 1-GPU workload
     stages = {k: {"ms_total": round(v[0], 3), "launches": int(v[1]),
                   "ms_avg": round(v[0] / v[1], 4) if v[1] else None} for k, v in timers.items() if v[1]}
@@ -654,7 +687,8 @@ def main():
     out = {
         "metric": "images/sec encoded + top-k retrieved, VLAD K256 RootSIFT",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        **({"exchange": exchange_mode} if world > 1 else {}),
+        **({"exchange": exchange_mode, "exchange_overlaps_own_block": bool(overlap and backend != "gloo")} if multi else {}),
+        **({"backend": "ONE-rank RCCL self-check of the multi-rank path: not a measurement"} if forced else {}),
         **({"backend": "gloo REHEARSAL (ranks share GPUs, host-staged collectives): not a measurement"} if backend == "gloo" else {}),
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "retrieval": args.retrieval,
@@ -667,7 +701,7 @@ def main():
                      "peak": 2500.0 if filtered[0] else FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / (2500.0 if filtered[0] else FP32_MFMA_PEAK_TFLOPS), 4),
                      "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flop_per_launch,
-                     "mfma_pipe_busy_frac": None if (world != 1 or N != 8189 or filtered[0]) else
+                     "mfma_pipe_busy_frac": None if (multi or N != 8189 or filtered[0]) else
                      pmc_mfma_busy("pvs::gemm_mfma_kernel", keep=lambda nm: not _gemm_is_f16(nm)),
                      "algorithmic_flop_per_launch": alg_flop,
                      "algorithmic_equiv_TFLOPs": round(alg_flop / (gemm_avg_ms * 1e-3) / 1e12, 2) if gemm_n else None, "avg_launch_ms": round(gemm_avg_ms, 4)},
@@ -695,18 +729,18 @@ def main():
             "queries_redone_exact": f_st["redone_exact"] if f_st else None}
         assert same_lists, "filtered retrieval differs from the exact path"
 
-    if args.pcie and world == 1:
+    if args.pcie and not multi:
         h_desc = desc.cpu().numpy()
         t1 = time.perf_counter()
         v = ctx.vlad_encode(cb, h_desc, offsets, kind)
         ctx.cosine_topk(v, v, TOPK)
         out["pcie_inclusive_images_per_s"] = round(N / (time.perf_counter() - t1), 1)
 
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and not multi:
         out["cpu_baseline"] = cpu_baseline(raw, offsets, tables["centroids"], enc_loc[:n_loc], N)
 
     print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -126,21 +126,28 @@ def _rows(n_total, world, r):
     return hi - lo
 
 
-def retrieve_symmetric(enc_all, inv_all, n_total: int, rank: int, world: int, k: int, ops, all_to_all, new_tensor):
+def retrieve_symmetric(enc_all, inv_all, n_total: int, rank: int, world: int, k: int, ops, all_to_all, new_tensor,
+                       own=None, before_cross=None):
     """Top-k of this rank's queries against the whole corpus, scoring each block pair once (see above).
+
+    own = (enc_loc, inv_loc) and before_cross (a callable) let the exchange overlap the (r, r) block: that block is scored from
+    the rank's local copy, then before_cross() must make the gathered rows of the OTHER ranks visible (e.g. wait on the
+    asynchronous all-gather) before the cross blocks are scored.
 
     enc_all (world*B, L) / inv_all (world*B,): the gathered encodings and inverse norms (padding rows unused).
     ops: DeviceOps-like.  all_to_all(out, inp): exchange of equal (B*k)-element slabs between ranks, e.g.
     torch.distributed.all_to_all_single.  new_tensor(shape, dtype, fill): allocator on the right device.
     Returns (idx (n_loc, k) int64, val (n_loc, k) float32)."""
-    st = symmetric_local(enc_all, inv_all, n_total, rank, world, k, ops, new_tensor)
+    st = symmetric_local(enc_all, inv_all, n_total, rank, world, k, ops, new_tensor, own=own, before_cross=before_cross)
     all_to_all(st["m_idx"][:world].reshape(-1), st["s_idx"].reshape(-1))
     all_to_all(st["m_val"][:world].reshape(-1), st["s_val"].reshape(-1))
     return symmetric_finish(st, ops, new_tensor)
 
 
-def symmetric_local(enc_all, inv_all, n_total: int, rank: int, world: int, k: int, ops, new_tensor) -> dict:
-    """Phase 1 (no communication): score this rank's block pairs; returns the send / merge buffers."""
+def symmetric_local(enc_all, inv_all, n_total: int, rank: int, world: int, k: int, ops, new_tensor, own=None,
+                    before_cross=None) -> dict:
+    """Phase 1 (no communication of its own): score this rank's block pairs; returns the send / merge buffers.
+    own / before_cross: see retrieve_symmetric."""
     import torch
     lo, hi, B = shard_range(n_total, world, rank)
     n_r = hi - lo
@@ -155,7 +162,13 @@ def symmetric_local(enc_all, inv_all, n_total: int, rank: int, world: int, k: in
 
     if n_r > 0:
         # ---- (r, r): symmetric kernel
-        ops.sym_topk(blk(enc_all, rank), n_r, blk(inv_all, rank), k, rank * B, own_i, own_v)
+        if own is not None:
+            ops.sym_topk(own[0], n_r, own[1], k, rank * B, own_i, own_v)
+        else:
+            ops.sym_topk(blk(enc_all, rank), n_r, blk(inv_all, rank), k, rank * B, own_i, own_v)
+    if before_cross is not None:                             # every rank, also one without rows: the exchange is collective
+        before_cross()
+    if n_r > 0:
         # ---- (r, r+1 .. r+h): full blocks, dual store; contiguous runs of blocks go in one launch
         h = (P - 1) // 2
         # contiguous runs of partner blocks (one launch each): a run ends at the wrap-around, after a short block

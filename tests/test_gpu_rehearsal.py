@@ -29,3 +29,29 @@ def test_multi_rank_bench_rehearsal(ranks, exchange):
     assert r.stderr.count("identical to the single-GPU ranking") == ranks, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == ranks and "REHEARSAL" in line["backend"] and line["exchange"] == exchange
+
+
+@pytest.mark.parametrize("retrieval", ["exact", "filtered"])
+def test_one_rank_rccl_self_check(retrieval):
+    """The SAME multi-rank code path on the measured transport: one rank, backend nccl (= RCCL) -- process group bound to the
+    device, the engine on the stream RCCL synchronises with, the asynchronous all-gather overlapped with the (r, r) block,
+    the all-to-all of the candidate lists -- checked bit for bit against the plain single-GPU retrieval."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PVS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PVS_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--images", "1030", "--no-cpu-baseline", "--retrieval", retrieval]
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stderr.count("identical to the single-GPU ranking") == 1, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "RCCL self-check" in line["backend"] and line["exchange_overlaps_own_block"] is True
