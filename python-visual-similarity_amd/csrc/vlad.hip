@@ -208,9 +208,13 @@ struct Assign16Args {
   int64_t* amb_rows;             // [gridDim][cap]: descriptors left to the exact kernel, one list per workgroup
   unsigned long long* amb_count; // [gridDim]
   int64_t cap;
+  int stagger;                   // head start of waves 0..3 over waves 4..7, in s_sleep(127) units (0: none)
 };
 
-template <int NT, int KIND, bool VEC>
+// STEPS: the number of 16-dim k-steps when it is known at compile time (8 for D_pad16 = 128), 0 = read it from the arguments.
+// With STEPS > 0 the whole cluster loop of a row block is straight-line code: table fragments are fetched from LDS one step
+// ahead of the MFMAs that use them, and the selection over one pair of tiles runs under the MFMAs of the next pair.
+template <int NT, int KIND, bool VEC, int STEPS>
 __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned int s_count;
@@ -234,6 +238,11 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
   __syncthreads();
   const float sqrt_d = sqrtf((float)a.D);
   int64_t* const my_rows = a.amb_rows + (int64_t)blockIdx.x * a.cap;
+  // The two waves of a SIMD (w and w + 4) would otherwise run their load / convert / MFMA / select phases in lockstep -- fair
+  // issue arbitration keeps equal waves aligned, so every phase runs alone and nothing overlaps.  Half a step of head start
+  // for one of them puts the MFMA phase of one wave under the load + VALU phase of the other.
+  if (a.stagger > 0 ? wave >= ASSIGN_THREADS / 128 : (wave & 1) != 0)
+    for (int s = 0; s < (a.stagger > 0 ? a.stagger : -a.stagger); ++s) __builtin_amdgcn_s_sleep(127);
 
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int64_t row = blk * ASSIGN_ROWS + wave * 32 + j;
@@ -310,6 +319,60 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
     const float m2s = -2.f * ldexpf(1.f, -(x_shift + a.c_shift));   // v = cn - 2 acc 2^-(shifts): one fma, the scale is exact
     float best = INFINITY, second = INFINITY;
     int bidx = 0;
+    if constexpr (STEPS > 0) {
+      constexpr int G2 = NT < 2 ? NT : 2;     // tiles per group: two accumulator sets alternate between groups
+      constexpr int NG = NT / G2;
+      f32x16 acc[2][G2];
+      f16x8_t fh[2][G2], fl[2][G2];
+      auto fetch = [&](int buf, int step) {
+        const int g = step / STEPS, t = step % STEPS;
+#pragma unroll
+        for (int tile = 0; tile < G2; ++tile) {
+          fh[buf][tile] = *reinterpret_cast<const f16x8_t*>(lds_h + (32 * (g * G2 + tile) + j) * stride + 16 * t + 8 * h);
+          fl[buf][tile] = *reinterpret_cast<const f16x8_t*>(lds_l + (32 * (g * G2 + tile) + j) * stride + 16 * t + 8 * h);
+        }
+      };
+      // selection over the 4 clusters (tile, q) of group g this lane holds in acc[ab][tile][4 q ..]: 20 VALU instructions
+      auto select4 = [&](int ab, int g, int part) {
+        const int tile = part >> 2, q = part & 3;
+        const int r0 = 32 * (g * G2 + tile) + 8 * q;
+        const float4 cn = *reinterpret_cast<const float4*>(lds_n + r0 + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(m2s, acc[ab][tile][4 * q + e], e == 0 ? cn.x : (e == 1 ? cn.y : (e == 2 ? cn.z : cn.w)));
+          const bool lt = v < best;          // ascending cluster order, strict '<': the first minimum stays
+          second = __builtin_amdgcn_fmed3f(best, second, v);
+          best = lt ? v : best;
+          bidx = lt ? (r0 + e) : bidx;       // the lane's 4 h is added after the loop
+        }
+      };
+      static_assert(G2 * 4 <= STEPS, "one selection part per k-step");
+      fetch(0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int ab = g & 1;
+#pragma unroll
+        for (int tile = 0; tile < G2; ++tile)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ab][tile][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < STEPS; ++t) {
+          const int step = g * STEPS + t, buf = step & 1;
+          if (step + 1 < NG * STEPS) fetch(buf ^ 1, step + 1);
+          __builtin_amdgcn_sched_barrier(0);     // the fetch stays AHEAD of this step's MFMAs (the scheduler sinks it otherwise)
+#pragma unroll
+          for (int tile = 0; tile < G2; ++tile) {
+            acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[buf][tile], xh[t], acc[ab][tile], 0, 0, 0);
+            acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[buf][tile], xl[t], acc[ab][tile], 0, 0, 0);
+            acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[buf][tile], xh[t], acc[ab][tile], 0, 0, 0);
+          }
+          if (g > 0 && t < G2 * 4) select4(ab ^ 1, g - 1, t);   // the previous group's selection, a part under each step's MFMAs
+          __builtin_amdgcn_sched_barrier(0);     // keep the steps apart: hoisting every fetch to the top spills
+        }
+      }
+#pragma unroll
+      for (int part = 0; part < G2 * 4; ++part) select4((NG - 1) & 1, NG - 1, part);
+    } else {
 #pragma unroll
     for (int g0 = 0; g0 < NT; g0 += G) {
       f32x16 acc[G];
@@ -339,12 +402,18 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float v = fmaf(m2s, acc[tile][4 * g + e], e == 0 ? cn.x : (e == 1 ? cn.y : (e == 2 ? cn.z : cn.w)));
-            // ascending cluster order: strict '<' keeps the first minimum; NaN never enters
-            if (v < best) { second = best; best = v; bidx = r0 + e; }
-            else if (v < second) second = v;
+            // ascending cluster order: strict '<' keeps the first minimum.  v is never NaN for a row that can settle (finite
+            // x and tables give finite products; padded clusters are +inf), and rows with a non-finite x are listed whatever
+            // comes out here.  Selects, not branches: as control flow this was ~2000 instructions per step.
+            const bool lt = v < best;
+            second = __builtin_amdgcn_fmed3f(best, second, v);       // best <= second: the median is the new runner-up
+            best = lt ? v : best;
+            bidx = lt ? (32 * (g0 + tile) + 8 * g + e) : bidx;       // the lane's 4 h is added after the loop
           }
         }
     }
+    }
+    bidx += 4 * h;
     {   // the two half-waves hold interleaved cluster subsets of the same descriptor
       const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
       const int oi = __shfl_xor(bidx, 32, 64);
@@ -400,9 +469,10 @@ static int launch_assign_kind(pvs_ctx* ctx, const AssignArgs& a, int nt, bool ve
 
 template <int NT, int KIND>
 static int launch_assign16_nt(pvs_ctx* ctx, const Assign16Args& p, bool vec, size_t lds, int grid) {
-  auto kv = assign16_kernel<NT, KIND, true>;
-  auto ks = assign16_kernel<NT, KIND, false>;
-  auto k = vec ? kv : ks;
+  auto kv = assign16_kernel<NT, KIND, true, 0>;
+  auto ks = assign16_kernel<NT, KIND, false, 0>;
+  auto k8 = assign16_kernel<NT, KIND, true, 8>;
+  auto k = vec ? (p.D_pad16 == 128 ? k8 : kv) : ks;
   PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(grid), dim3(ASSIGN_THREADS), lds, ctx->stream, p);
   PVS_HIP(hipGetLastError());
@@ -459,7 +529,8 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(ws);
     int64_t* rows = reinterpret_cast<int64_t*>(ws + cnt_b);
     Assign16Args p{d_desc, total, cb->D, ld, static_cast<const _Float16*>(cb->d_c16), cb->d_cnorm, cb->K_pad, cb->D_pad16,
-                   cb->c16_shift, cb->cmax, d_labels, rows, cnt, cap};
+                   cb->c16_shift, cb->cmax, d_labels, rows, cnt, cap, 2};
+    if (const char* e = getenv("PVS_ASSIGN_STAGGER")) p.stagger = atoi(e);
     const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4;
     PVS_TRY(launch_assign16(ctx, p, kind, cb->K_pad / 32, vec, lds16, grid));
     a.rows = rows;
