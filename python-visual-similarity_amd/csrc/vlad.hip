@@ -208,7 +208,6 @@ struct Assign16Args {
   int64_t* amb_rows;             // [gridDim][cap]: descriptors left to the exact kernel, one list per workgroup
   unsigned long long* amb_count; // [gridDim]
   int64_t cap;
-  int stagger;                   // head start of waves 0..3 over waves 4..7, in s_sleep(127) units (0: none)
 };
 
 // STEPS: the number of 16-dim k-steps when it is known at compile time (8 for D_pad16 = 128), 0 = read it from the arguments.
@@ -238,18 +237,32 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
   __syncthreads();
   const float sqrt_d = sqrtf((float)a.D);
   int64_t* const my_rows = a.amb_rows + (int64_t)blockIdx.x * a.cap;
-  // The two waves of a SIMD (w and w + 4) would otherwise run their load / convert / MFMA / select phases in lockstep -- fair
-  // issue arbitration keeps equal waves aligned, so every phase runs alone and nothing overlaps.  Half a step of head start
-  // for one of them puts the MFMA phase of one wave under the load + VALU phase of the other.
-  if (a.stagger > 0 ? wave >= ASSIGN_THREADS / 128 : (wave & 1) != 0)
-    for (int s = 0; s < (a.stagger > 0 ? a.stagger : -a.stagger); ++s) __builtin_amdgcn_s_sleep(127);
+
+  // STEPS > 0 (launched only for D = 128) with float rows: the rows of the NEXT block are requested before this block's MFMA
+  // phase and land under it.  Loads are unconditional: a row past the end reads the last row instead, its result is not stored.
+  constexpr bool PREFETCH = STEPS > 0 && VEC && KIND != PVS_DESC_U8_ROOTSIFT;
+  float xf[8][8];
+  auto request_rows = [&](int64_t blk_) {
+    int64_t r = blk_ * ASSIGN_ROWS + wave * 32 + j;
+    r = r < a.total ? r : a.total - 1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 v0 = load4<KIND>(a.X, r, a.ld, 16 * t + 4 * h);
+      const float4 v1 = load4<KIND>(a.X, r, a.ld, 16 * t + 4 * h + 8);
+      xf[t][0] = v0.x; xf[t][1] = v0.y; xf[t][2] = v0.z; xf[t][3] = v0.w;
+      xf[t][4] = v1.x; xf[t][5] = v1.y; xf[t][6] = v1.z; xf[t][7] = v1.w;
+    }
+  };
+  if constexpr (PREFETCH) {
+    if (blockIdx.x < nblocks) request_rows(blockIdx.x);
+  }
 
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int64_t row = blk * ASSIGN_ROWS + wave * 32 + j;
     const bool rvalid = row < a.total;
     // ---- this lane's half of the row: of every 16 dims the four at 4h and the four at 8 + 4h (the lane pair (j, 0), (j, 1)
     // reads 32 contiguous bytes per load; the fp16 tables are stored in the same order)
-    float xf[8][8];
+    if constexpr (!PREFETCH) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -273,6 +286,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
           }
         }
       }
+    }
     }
     if constexpr (DescTraits<KIND>::rootsift) {
       float s = 0.f;
@@ -319,11 +333,23 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
     const float m2s = -2.f * ldexpf(1.f, -(x_shift + a.c_shift));   // v = cn - 2 acc 2^-(shifts): one fma, the scale is exact
     float best = INFINITY, second = INFINITY;
     int bidx = 0;
+    if constexpr (PREFETCH) {
+      __builtin_amdgcn_sched_barrier(0);      // after the conversion: the old row registers are dead, the new ones not yet live
+      if (blk + gridDim.x < nblocks) request_rows(blk + gridDim.x);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (STEPS > 0) {
       constexpr int G2 = NT < 2 ? NT : 2;     // tiles per group: two accumulator sets alternate between groups
       constexpr int NG = NT / G2;
       f32x16 acc[2][G2];
       f16x8_t fh[2][G2], fl[2][G2];
+      float4 cnb;                             // the table norms of the NEXT step's selection part, read at the end of a step
+      int nh = 4 * h;
+      asm volatile("" : "+v"(nh));            // opaque per block: ONE base register + immediate offsets (hoisted out of the
+                                              // block loop, the 32 precomputed addresses were spilled and reloaded per step)
+      auto cn_of = [&](int g, int part) {
+        return *reinterpret_cast<const float4*>(lds_n + nh + (32 * (g * G2 + (part >> 2)) + 8 * (part & 3)));
+      };
       auto fetch = [&](int buf, int step) {
         const int g = step / STEPS, t = step % STEPS;
 #pragma unroll
@@ -333,10 +359,9 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
         }
       };
       // selection over the 4 clusters (tile, q) of group g this lane holds in acc[ab][tile][4 q ..]: 20 VALU instructions
-      auto select4 = [&](int ab, int g, int part) {
+      auto select4 = [&](int ab, int g, int part, const float4 cn) {
         const int tile = part >> 2, q = part & 3;
         const int r0 = 32 * (g * G2 + tile) + 8 * q;
-        const float4 cn = *reinterpret_cast<const float4*>(lds_n + r0 + 4 * h);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = fmaf(m2s, acc[ab][tile][4 * q + e], e == 0 ? cn.x : (e == 1 ? cn.y : (e == 2 ? cn.z : cn.w)));
@@ -360,18 +385,27 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
           const int step = g * STEPS + t, buf = step & 1;
           if (step + 1 < NG * STEPS) fetch(buf ^ 1, step + 1);
           __builtin_amdgcn_sched_barrier(0);     // the fetch stays AHEAD of this step's MFMAs (the scheduler sinks it otherwise)
+          // the three products of a tile go to the same accumulator in a fixed order; the tiles alternate so that an MFMA
+          // never waits for the result of the one issued just before it
 #pragma unroll
-          for (int tile = 0; tile < G2; ++tile) {
+          for (int tile = 0; tile < G2; ++tile)
             acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[buf][tile], xh[t], acc[ab][tile], 0, 0, 0);
+#pragma unroll
+          for (int tile = 0; tile < G2; ++tile)
             acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[buf][tile], xl[t], acc[ab][tile], 0, 0, 0);
+#pragma unroll
+          for (int tile = 0; tile < G2; ++tile)
             acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[buf][tile], xh[t], acc[ab][tile], 0, 0, 0);
+          if (g > 0 && t < G2 * 4) select4(ab ^ 1, g - 1, t, cnb);   // the previous group's selection, a part under each step's MFMAs
+          {
+            const int g1 = (step + 1) / STEPS, t1 = (step + 1) % STEPS;
+            if (step + 1 < NG * STEPS && g1 > 0 && t1 < G2 * 4) cnb = cn_of(g1 - 1, t1);
           }
-          if (g > 0 && t < G2 * 4) select4(ab ^ 1, g - 1, t);   // the previous group's selection, a part under each step's MFMAs
           __builtin_amdgcn_sched_barrier(0);     // keep the steps apart: hoisting every fetch to the top spills
         }
       }
 #pragma unroll
-      for (int part = 0; part < G2 * 4; ++part) select4((NG - 1) & 1, NG - 1, part);
+      for (int part = 0; part < G2 * 4; ++part) select4((NG - 1) & 1, NG - 1, part, cn_of(NG - 1, part));
     } else {
 #pragma unroll
     for (int g0 = 0; g0 < NT; g0 += G) {
@@ -472,7 +506,7 @@ static int launch_assign16_nt(pvs_ctx* ctx, const Assign16Args& p, bool vec, siz
   auto kv = assign16_kernel<NT, KIND, true, 0>;
   auto ks = assign16_kernel<NT, KIND, false, 0>;
   auto k8 = assign16_kernel<NT, KIND, true, 8>;
-  auto k = vec ? (p.D_pad16 == 128 ? k8 : kv) : ks;
+  auto k = vec ? (p.D == 128 && p.D_pad16 == 128 ? k8 : kv) : ks;
   PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(grid), dim3(ASSIGN_THREADS), lds, ctx->stream, p);
   PVS_HIP(hipGetLastError());
@@ -529,8 +563,7 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(ws);
     int64_t* rows = reinterpret_cast<int64_t*>(ws + cnt_b);
     Assign16Args p{d_desc, total, cb->D, ld, static_cast<const _Float16*>(cb->d_c16), cb->d_cnorm, cb->K_pad, cb->D_pad16,
-                   cb->c16_shift, cb->cmax, d_labels, rows, cnt, cap, 2};
-    if (const char* e = getenv("PVS_ASSIGN_STAGGER")) p.stagger = atoi(e);
+                   cb->c16_shift, cb->cmax, d_labels, rows, cnt, cap};
     const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4;
     PVS_TRY(launch_assign16(ctx, p, kind, cb->K_pad / 32, vec, lds16, grid));
     a.rows = rows;
