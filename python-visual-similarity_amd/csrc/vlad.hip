@@ -837,6 +837,192 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming variant for tables whose K x D accumulators fit in LDS (K D <= 32768 floats, D <= 128, D % 4 == 0): the image's
+// rows are read IN DESCRIPTOR ORDER (the block of an image is one contiguous HBM range) instead of cluster by cluster.
+// 16 units (half-waves) split the clusters by `label & 15`; a stable counting sort on that 4-bit key gives every unit its
+// rows in descriptor order, and the unit adds them one after the other into the cluster's accumulator row in LDS
+// (read - add - write of one wave execute in order), so every cluster still sums its members sequentially in descriptor
+// order: the same fp32 result as vlad_aggregate_kernel, bit for bit.  One workgroup (8 waves) per image, one per CU.
+constexpr int ST_THREADS = 512;
+constexpr int ST_WAVES = ST_THREADS / 64;
+constexpr int ST_UNITS = 16;
+constexpr int ST_PF = 8;
+
+template <int KIND>
+__global__ __launch_bounds__(ST_THREADS) void vlad_stream_kernel(AggArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int K = a.K, D = a.D;
+  float* accs = reinterpret_cast<float*>(smem);                       // [K][D]
+  int* hist = reinterpret_cast<int*>(accs + (size_t)K * D);           // [ST_WAVES][ST_UNITS] counts, then cursors
+  int* start = hist + ST_WAVES * ST_UNITS;                            // [ST_UNITS + 1]
+  float* rowsq = reinterpret_cast<float*>(start + ST_UNITS + 1);      // [K]
+  uint16_t* order = reinterpret_cast<uint16_t*>(rowsq + K);           // [AGG_CHUNK] row of the chunk, unit by unit
+  uint16_t* olab = order + AGG_CHUNK;                                 // [AGG_CHUNK] its label
+
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int unit = tid >> 5, gl = tid & 31, d0 = 4 * gl;
+  const bool dlive = d0 < D;
+  const int64_t row0 = a.offsets[img];
+  const int64_t n = a.offsets[img + 1] - row0;
+  float* out_img = a.out + (int64_t)img * K * D;
+
+  for (int i = tid * 4; i < K * D; i += ST_THREADS * 4) *reinterpret_cast<float4*>(accs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const int64_t nchunks = (n + AGG_CHUNK - 1) / AGG_CHUNK;
+  for (int64_t ch = 0; ch < nchunks; ++ch) {
+    const int64_t cbase = row0 + ch * AGG_CHUNK;
+    const int cn = (int)min((int64_t)AGG_CHUNK, n - ch * AGG_CHUNK);
+    // ---- 1. per-wave histograms of the unit key
+    if (tid < ST_WAVES * ST_UNITS) hist[tid] = 0;
+    __syncthreads();
+    const int per_wave = (cn + ST_WAVES - 1) / ST_WAVES;
+    const int wbeg = min(cn, wave * per_wave), wend = min(cn, wbeg + per_wave);
+    for (int i = wbeg + lane; i < wend; i += 64) atomicAdd(&hist[wave * ST_UNITS + (a.labels[cbase + i] & (ST_UNITS - 1))], 1);
+    __syncthreads();
+    // ---- 2. exclusive scan, key major / wave minor
+    if (tid == 0) {
+      int run = 0;
+      for (int u = 0; u < ST_UNITS; ++u) {
+        start[u] = run;
+        for (int w = 0; w < ST_WAVES; ++w) {
+          const int c = hist[w * ST_UNITS + u];
+          hist[w * ST_UNITS + u] = run;
+          run += c;
+        }
+      }
+      start[ST_UNITS] = run;
+    }
+    __syncthreads();
+    // ---- 3. stable placement (as in vlad_aggregate_kernel, on the 4-bit key)
+    for (int i0 = wbeg; i0 < wend; i0 += 64) {
+      const int i = i0 + lane;
+      const bool v = i < wend;
+      const int label = v ? a.labels[cbase + i] : -1;
+      const int key = v ? (label & (ST_UNITS - 1)) : -1;
+      unsigned long long peers = __ballot(v);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const unsigned long long bal = __ballot((key >> b) & 1);
+        peers &= ((key >> b) & 1) ? bal : ~bal;
+      }
+      if (v) {
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        const int basepos = hist[wave * ST_UNITS + key];
+        order[basepos + rank] = (uint16_t)i;
+        olab[basepos + rank] = (uint16_t)label;
+        if ((peers >> lane) == 1ull) hist[wave * ST_UNITS + key] = basepos + rank + 1;
+      }
+    }
+    __syncthreads();
+    // ---- 4. every unit walks its rows in descriptor order: two register sets of ST_PF rows, the loads of one set are in
+    //         flight while the other is added
+    const int s = start[unit], e = start[unit + 1];
+    float4 xa[ST_PF], ca[ST_PF], xb[ST_PF], cb[ST_PF];
+    int la[ST_PF], lb[ST_PF];
+    auto request = [&](int p0, float4 (&x)[ST_PF], float4 (&c)[ST_PF], int (&lab)[ST_PF]) {
+#pragma unroll
+      for (int u = 0; u < ST_PF; ++u) {
+        const bool live = p0 + u < e;
+        const int pos = live ? p0 + u : p0;
+        const int64_t row = cbase + order[pos];
+        lab[u] = olab[pos];
+        x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        c[u] = x[u];
+        if (live && dlive) {
+          x[u] = load4<KIND>(a.X, row, a.ld, d0);
+          c[u] = *reinterpret_cast<const float4*>(a.cent + (int64_t)lab[u] * D + d0);
+        }
+      }
+    };
+    auto consume = [&](int p0, float4 (&x)[ST_PF], const float4 (&c)[ST_PF], const int (&lab)[ST_PF]) {
+#pragma unroll
+      for (int u = 0; u < ST_PF; ++u) {
+        if (p0 + u < e) {   // uniform over the unit
+          if constexpr (DescTraits<KIND>::rootsift) {
+            float sm = (x[u].x + x[u].y) + (x[u].z + x[u].w);   // integer-valued: exact in any order
+            sm = wave_sum_xor(sm, 32);
+            x[u].x = rootsift_apply(x[u].x, sm); x[u].y = rootsift_apply(x[u].y, sm);
+            x[u].z = rootsift_apply(x[u].z, sm); x[u].w = rootsift_apply(x[u].w, sm);
+          }
+          if (dlive) {
+            float4* ap = reinterpret_cast<float4*>(accs + lab[u] * D + d0);
+            float4 t = *ap;
+            t.x += (x[u].x - c[u].x); t.y += (x[u].y - c[u].y); t.z += (x[u].z - c[u].z); t.w += (x[u].w - c[u].w);
+            *ap = t;
+          }
+        }
+      }
+    };
+    if (s < e) request(s, xa, ca, la);
+    for (int p0 = s; p0 < e; p0 += 2 * ST_PF) {
+      if (p0 + ST_PF < e) request(p0 + ST_PF, xb, cb, lb);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(p0, xa, ca, la);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p0 + ST_PF < e) {
+        if (p0 + 2 * ST_PF < e) request(p0 + 2 * ST_PF, xa, ca, la);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(p0 + ST_PF, xb, cb, lb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+  if (nchunks == 0) __syncthreads();
+
+  // ---- K3 per cluster row (one unit per row), then the whole-vector 1 / ||.||_2
+  for (int k = unit; k < K; k += ST_UNITS) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (dlive) {
+      const float4 t = *reinterpret_cast<const float4*>(accs + k * D + d0);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    if (a.norm_mode == 4) {
+      if (dlive) *reinterpret_cast<float4*>(out_img + (int64_t)k * D + d0) = make_float4(v[0], v[1], v[2], v[3]);
+      if (gl == 0) rowsq[k] = 0.f;
+      continue;
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = dlive ? power_norm(v[q], a.power) : 0.f;
+      const float t = norm_accum(v[q], a.norm_mode, a.norm_p);
+      part = a.norm_mode == 3 ? fmaxf(part, t) : part + t;
+    }
+    float nrm = a.norm_mode == 3 ? wave_max_xor(part, 32) : wave_sum_xor(part, 32);
+    if (a.norm_mode == 2) nrm = sqrtf(nrm);
+    else if (a.norm_mode == 0) nrm = powf(nrm, 1.f / a.norm_p);
+    const float den = nrm + a.eps;
+    float sq = 0.f, o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      o[q] = v[q] / den;
+      if (dlive) sq += o[q] * o[q];
+    }
+    if (dlive) *reinterpret_cast<float4*>(out_img + (int64_t)k * D + d0) = make_float4(o[0], o[1], o[2], o[3]);
+    sq = wave_sum_xor(sq, 32);
+    if (gl == 0) rowsq[k] = sq;
+  }
+  __syncthreads();
+  if (a.inv_norm != nullptr && wave == 0) {
+    float s2 = 0.f;
+    for (int k = lane; k < K; k += 64) s2 += rowsq[k];
+    s2 = wave_sum_xor(s2, 64);
+    if (lane == 0) a.inv_norm[img] = s2 > 0.f ? 1.f / sqrtf(s2) : 1.f;
+  }
+}
+
+template <int KIND>
+static int launch_stream_inst(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, size_t lds) {
+  auto k = vlad_stream_kernel<KIND>;
+  PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3((unsigned)n_images), dim3(ST_THREADS), lds, ctx->stream, a);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
 template <int KIND, int GROUP, int VW, int NREG>
 static int launch_agg_inst(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, size_t lds) {
   auto k = vlad_aggregate_kernel<KIND, GROUP, VW, NREG>;
@@ -885,6 +1071,18 @@ int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_de
                    ((reinterpret_cast<uintptr_t>(d_out) % 16) == 0);
   const size_t lds = (size_t)(AGG_WAVES * cb->K + cb->K + 1) * 4 + (size_t)cb->K * 4 + (size_t)AGG_WAVES * 4 + (size_t)AGG_CHUNK * 2 + 16;
   ScopedTimer tm(ctx, T_AGGREGATE);
+  // accumulators in LDS, rows streamed in descriptor order (see vlad_stream_kernel): experimental, PVS_AGG_STREAM=1 selects it
+  const size_t lds_s = (size_t)cb->K * cb->D * 4 + (size_t)(ST_WAVES * ST_UNITS + ST_UNITS + 1) * 4 + (size_t)cb->K * 4 + (size_t)AGG_CHUNK * 4 + 16;
+  static const bool stream_ok = [] { const char* e = getenv("PVS_AGG_STREAM"); return e != nullptr && atoi(e) != 0; }();
+  if (stream_ok && vec && cb->D <= 128 && (size_t)cb->K * cb->D <= 32768 && lds_s <= 160 * 1024 - 512 &&
+      (reinterpret_cast<uintptr_t>(cb->d_cent) % 16) == 0) {
+    switch (kind) {
+      case PVS_DESC_F32: return launch_stream_inst<PVS_DESC_F32>(ctx, a, n_images, lds_s);
+      case PVS_DESC_F32_ROOTSIFT: return launch_stream_inst<PVS_DESC_F32_ROOTSIFT>(ctx, a, n_images, lds_s);
+      case PVS_DESC_U8_ROOTSIFT: return launch_stream_inst<PVS_DESC_U8_ROOTSIFT>(ctx, a, n_images, lds_s);
+      default: PVS_FAIL(PVS_ERR_INVALID, "unknown descriptor kind %d", kind);
+    }
+  }
   switch (kind) {
     case PVS_DESC_F32: return launch_agg_kind<PVS_DESC_F32>(ctx, a, n_images, lds, vec);
     case PVS_DESC_F32_ROOTSIFT: return launch_agg_kind<PVS_DESC_F32_ROOTSIFT>(ctx, a, n_images, lds, vec);
