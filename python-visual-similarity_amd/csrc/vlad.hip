@@ -882,17 +882,30 @@ __global__ __launch_bounds__(ST_THREADS) void vlad_stream_kernel(AggArgs a) {
     for (int i = wbeg + lane; i < wend; i += 64) atomicAdd(&hist[wave * ST_UNITS + (a.labels[cbase + i] & (ST_UNITS - 1))], 1);
     __syncthreads();
     // ---- 2. exclusive scan, key major / wave minor
-    if (tid == 0) {
-      int run = 0;
-      for (int u = 0; u < ST_UNITS; ++u) {
-        start[u] = run;
-        for (int w = 0; w < ST_WAVES; ++w) {
-          const int c = hist[w * ST_UNITS + u];
-          hist[w * ST_UNITS + u] = run;
-          run += c;
-        }
+    if (wave == 0) {      // lanes 0..15: one key each, prefix over the keys by shuffles
+      const int u = lane & (ST_UNITS - 1);
+      int c[ST_WAVES], tot = 0;
+#pragma unroll
+      for (int w = 0; w < ST_WAVES; ++w) {
+        c[w] = hist[w * ST_UNITS + u];
+        tot += c[w];
       }
-      start[ST_UNITS] = run;
+      int incl = tot;
+#pragma unroll
+      for (int d = 1; d < ST_UNITS; d <<= 1) {
+        const int o = __shfl_up(incl, d, ST_UNITS);
+        if (u >= d) incl += o;
+      }
+      if (lane < ST_UNITS) {
+        int run = incl - tot;
+        start[u] = run;
+#pragma unroll
+        for (int w = 0; w < ST_WAVES; ++w) {
+          hist[w * ST_UNITS + u] = run;
+          run += c[w];
+        }
+        if (u == ST_UNITS - 1) start[ST_UNITS] = run;
+      }
     }
     __syncthreads();
     // ---- 3. stable placement (as in vlad_aggregate_kernel, on the 4-bit key)
@@ -921,19 +934,17 @@ __global__ __launch_bounds__(ST_THREADS) void vlad_stream_kernel(AggArgs a) {
     const int s = start[unit], e = start[unit + 1];
     float4 xa[ST_PF], ca[ST_PF], xb[ST_PF], cb[ST_PF];
     int la[ST_PF], lb[ST_PF];
+    // requests are unconditional (a position past the unit's end reads the unit's last row again, a lane past D the last
+    // four dims): no branch between a request and the additions that wait for it, so the counters stay exact
+    const int dl = dlive ? d0 : D - 4;
     auto request = [&](int p0, float4 (&x)[ST_PF], float4 (&c)[ST_PF], int (&lab)[ST_PF]) {
 #pragma unroll
       for (int u = 0; u < ST_PF; ++u) {
-        const bool live = p0 + u < e;
-        const int pos = live ? p0 + u : p0;
+        const int pos = min(p0 + u, e - 1);
         const int64_t row = cbase + order[pos];
         lab[u] = olab[pos];
-        x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        c[u] = x[u];
-        if (live && dlive) {
-          x[u] = load4<KIND>(a.X, row, a.ld, d0);
-          c[u] = *reinterpret_cast<const float4*>(a.cent + (int64_t)lab[u] * D + d0);
-        }
+        x[u] = load4<KIND>(a.X, row, a.ld, dl);
+        c[u] = *reinterpret_cast<const float4*>(a.cent + (int64_t)lab[u] * D + dl);
       }
     };
     auto consume = [&](int p0, float4 (&x)[ST_PF], const float4 (&c)[ST_PF], const int (&lab)[ST_PF]) {
@@ -941,7 +952,7 @@ __global__ __launch_bounds__(ST_THREADS) void vlad_stream_kernel(AggArgs a) {
       for (int u = 0; u < ST_PF; ++u) {
         if (p0 + u < e) {   // uniform over the unit
           if constexpr (DescTraits<KIND>::rootsift) {
-            float sm = (x[u].x + x[u].y) + (x[u].z + x[u].w);   // integer-valued: exact in any order
+            float sm = dlive ? (x[u].x + x[u].y) + (x[u].z + x[u].w) : 0.f;   // integer-valued: exact in any order
             sm = wave_sum_xor(sm, 32);
             x[u].x = rootsift_apply(x[u].x, sm); x[u].y = rootsift_apply(x[u].y, sm);
             x[u].z = rootsift_apply(x[u].z, sm); x[u].w = rootsift_apply(x[u].w, sm);
@@ -955,14 +966,14 @@ __global__ __launch_bounds__(ST_THREADS) void vlad_stream_kernel(AggArgs a) {
         }
       }
     };
-    if (s < e) request(s, xa, ca, la);
-    for (int p0 = s; p0 < e; p0 += 2 * ST_PF) {
-      if (p0 + ST_PF < e) request(p0 + ST_PF, xb, cb, lb);
-      __builtin_amdgcn_sched_barrier(0);
-      consume(p0, xa, ca, la);
-      __builtin_amdgcn_sched_barrier(0);
-      if (p0 + ST_PF < e) {
-        if (p0 + 2 * ST_PF < e) request(p0 + 2 * ST_PF, xa, ca, la);
+    if (s < e) {
+      request(s, xa, ca, la);
+      for (int p0 = s; p0 < e; p0 += 2 * ST_PF) {
+        request(p0 + ST_PF, xb, cb, lb);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(p0, xa, ca, la);
+        __builtin_amdgcn_sched_barrier(0);
+        request(p0 + 2 * ST_PF, xa, ca, la);
         __builtin_amdgcn_sched_barrier(0);
         consume(p0 + ST_PF, xb, cb, lb);
         __builtin_amdgcn_sched_barrier(0);
