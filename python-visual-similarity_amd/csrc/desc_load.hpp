@@ -30,6 +30,31 @@ __device__ __forceinline__ float rootsift_apply(float raw, float row_sum) {
   return sqrtf(raw / (row_sum + 1e-7f));
 }
 
+// The RootSIFT transform of one row: sqrt(raw / (row_sum + 1e-7f)) per element, correctly rounded division and square root
+// (what NumPy computes).  For uint8 rows the value depends only on (raw, row_sum), raw in 0..255 <= row_sum <= 128 * 255, and a
+// shorter sequence gives the same bits for EVERY such pair: one IEEE reciprocal per row, then q = raw r refined by one
+// fma pair, g = q rsq(q) refined by one fma pair -- 10 instructions per element instead of ~22.  Checked exhaustively on the
+// device against the IEEE expression (csrc/bench/rootsift_exhaustive.hip: 0 of 8.3 M pairs differ).
+template <int KIND>
+struct RootsiftRow {
+  float d, r;
+  __device__ __forceinline__ explicit RootsiftRow(float row_sum)
+      : d(row_sum + 1e-7f), r(KIND == PVS_DESC_U8_ROOTSIFT ? 1.0f / (row_sum + 1e-7f) : 0.f) {}
+  __device__ __forceinline__ float operator()(float raw) const {
+    if (KIND == PVS_DESC_U8_ROOTSIFT && d <= 32640.5f) {   // the checked domain (D <= 128); longer rows take the IEEE path
+      float q = raw * r;
+      q = __builtin_fmaf(__builtin_fmaf(-q, d, raw), r, q);
+      const float rs = __builtin_amdgcn_rsqf(q);
+      float g = q * rs;
+      const float h = 0.5f * rs;
+      g = __builtin_fmaf(__builtin_fmaf(-g, g, q), h, g);
+      return q == 0.f ? 0.f : g;
+    } else {
+      return sqrtf(raw / d);
+    }
+  }
+};
+
 // 4 consecutive elements starting at column d (d % 4 == 0, row 16-B aligned for f32 / 4-B for u8).
 template <int KIND>
 __device__ __forceinline__ float4 load4(const void* base, int64_t row, int ld, int d) {

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void materialise_kernel(const void* __restrict
   s = wave_sum_xor(s, 64);
   for (int d = lane; d < D; d += 64) {
     const float v = load1<KIND>(X, row, D, d);
-    out[row * D + d] = DescTraits<KIND>::rootsift ? rootsift_apply(v, s) : v;
+    out[row * D + d] = DescTraits<KIND>::rootsift ? RootsiftRow<KIND>(s)(v) : v;
   }
 }
 

@@ -128,12 +128,13 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign_kernel(AssignArgs a)
 #pragma unroll
           for (int t = 0; t < 16; ++t) s += (xb[t].x + xb[t].y) + (xb[t].z + xb[t].w);
           s += __shfl_xor(s, 32, 64);
+          const RootsiftRow<KIND> rr(s);
 #pragma unroll
           for (int t = 0; t < 16; ++t) {
-            xb[t].x = rootsift_apply(xb[t].x, s);
-            xb[t].y = rootsift_apply(xb[t].y, s);
-            xb[t].z = rootsift_apply(xb[t].z, s);
-            xb[t].w = rootsift_apply(xb[t].w, s);
+            xb[t].x = rr(xb[t].x);
+            xb[t].y = rr(xb[t].y);
+            xb[t].z = rr(xb[t].z);
+            xb[t].w = rr(xb[t].w);
           }
         }
 
@@ -295,10 +296,11 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
 #pragma unroll
         for (int q = 0; q < 8; ++q) s += xf[t][q];
       s += __shfl_xor(s, 32, 64);   // integer-valued rows: the sum is exact, any order
+      const RootsiftRow<KIND> rr(s);
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) xf[t][q] = rootsift_apply(xf[t][q], s);
+        for (int q = 0; q < 8; ++q) xf[t][q] = rr(xf[t][q]);
     }
     // ---- row norm, row scale (largest |x| 2^shift in [2^12, 2^13)), hi / lo halves
     float n2 = 0.f, amax = 0.f;
@@ -755,10 +757,11 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
 #pragma unroll
                 for (int q = 0; q < VW; ++q) sm += x[u][r][q];
               sm = wave_sum_xor(sm, GROUP);
+              const RootsiftRow<KIND> rr(sm);
 #pragma unroll
               for (int r = 0; r < NREG; ++r)
 #pragma unroll
-                for (int q = 0; q < VW; ++q) x[u][r][q] = rootsift_apply(x[u][r][q], sm);
+                for (int q = 0; q < VW; ++q) x[u][r][q] = rr(x[u][r][q]);
             }
 #pragma unroll
             for (int r = 0; r < NREG; ++r)
@@ -954,8 +957,9 @@ __global__ __launch_bounds__(ST_THREADS) void vlad_stream_kernel(AggArgs a) {
           if constexpr (DescTraits<KIND>::rootsift) {
             float sm = dlive ? (x[u].x + x[u].y) + (x[u].z + x[u].w) : 0.f;   // integer-valued: exact in any order
             sm = wave_sum_xor(sm, 32);
-            x[u].x = rootsift_apply(x[u].x, sm); x[u].y = rootsift_apply(x[u].y, sm);
-            x[u].z = rootsift_apply(x[u].z, sm); x[u].w = rootsift_apply(x[u].w, sm);
+            const RootsiftRow<KIND> rr(sm);
+            x[u].x = rr(x[u].x); x[u].y = rr(x[u].y);
+            x[u].z = rr(x[u].z); x[u].w = rr(x[u].w);
           }
           if (dlive) {
             float4* ap = reinterpret_cast<float4*>(accs + lab[u] * D + d0);
