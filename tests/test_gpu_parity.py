@@ -943,3 +943,29 @@ def test_small_k_kernel_equals_the_radix_select(gpu_ctx, nq, N, k, monkeypatch):
         out.append((idx.cpu().numpy(), val.cpu().numpy()))
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+
+
+def test_u8_rootsift_short_sequence_equals_ieee(gpu_ctx):
+    """uint8 rows take a shorter RootSIFT sequence (one reciprocal per row, fma-refined quotient and rsq-based root;
+    desc_load.hpp:RootsiftRow) that must give NumPy's bits for every (element, row sum) pair.  csrc/bench/rootsift_exhaustive.hip
+    checks all 8.3 M pairs on the device; here: 3*10^5 rows of every density through the C-ABI against the oracle, including the
+    one-element rows (element = sum), the all-255 row and the empty row."""
+    import torch
+    rng = np.random.default_rng(5)
+    blocks = []
+    for hi, p in [(256, 1.0), (256, 0.5), (256, 0.1), (32, 0.7), (4, 0.3), (256, 0.02), (2, 0.5), (120, 0.9)]:
+        b = rng.integers(0, hi, (37500, 128), dtype=np.uint8)
+        b[rng.random(b.shape) > p] = 0
+        blocks.append(b)
+    single = np.zeros((256, 128), np.uint8)
+    single[np.arange(256), rng.integers(0, 128, 256)] = np.arange(256)
+    blocks += [single, np.full((1, 128), 255, np.uint8), np.zeros((1, 128), np.uint8)]
+    raw = np.ascontiguousarray(np.concatenate(blocks))
+    dev = torch.device("cuda", 0)
+    d_raw = torch.from_numpy(raw).to(dev)
+    d_out = torch.empty(raw.shape, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.materialise_dev(d_raw.data_ptr(), DESC_U8_ROOTSIFT, 128, raw.shape[0], d_out.data_ptr())
+    gpu_ctx.sync()
+    want = orc.rootsift(raw)
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
