@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PVS_VERSION 100 /* 0.1.0 */
+#define PVS_VERSION 101 /* 0.1.1 */
 
 typedef enum {
   PVS_OK = 0,
@@ -48,6 +48,16 @@ typedef enum {
   PVS_DESC_F32_ROOTSIFT = 1, /* float32 raw SIFT rows (0..255), RootSIFT applied on the fly  */
   PVS_DESC_U8_ROOTSIFT = 2   /* uint8  raw SIFT rows, RootSIFT applied on the fly (4x fewer HBM bytes) */
 } pvs_desc_kind;
+
+/* Behaviour switches of a context (pvs_set_option).  The defaults are the product path; the other values exist so that
+ * tests and benchmarks can pin one of several implementations that must agree bit for bit. */
+typedef enum {
+  PVS_OPT_ASSIGN_PREFILTER = 0, /* 1 (default): fp16 MFMA prefilter + exact pass on near ties; 0: exact f32 MFMA kernel only      */
+  PVS_OPT_VLAD_PATH = 1,        /* 0 (default): fused one-read encode when the shape qualifies, else 1; 1: assign + gather         */
+                                /* aggregate (two reads); 2: assign + streaming aggregate; 3: fused, error if the shape does not qualify */
+  PVS_OPT_TOPK_SELECT_ONLY = 2, /* 0 (default): k <= 16 takes the k-rounds kernel; 1: always the radix-select kernel               */
+  PVS_OPT_COUNT_ = 3
+} pvs_option;
 
 typedef struct pvs_ctx pvs_ctx;
 typedef struct pvs_codebook pvs_codebook; /* KMeans.cluster_centers_ (K,D) f32 + ||c||^2                */
@@ -73,6 +83,8 @@ int pvs_destroy(pvs_ctx* ctx);
 int pvs_sync(pvs_ctx* ctx);
 void* pvs_stream(pvs_ctx* ctx);
 int pvs_device_name(pvs_ctx* ctx, char* buf, size_t buflen);
+int pvs_set_option(pvs_ctx* ctx, int option, int value);
+int pvs_get_option(pvs_ctx* ctx, int option, int* value);
 
 /* plain device memory for hosts that do not use torch */
 int pvs_malloc(pvs_ctx* ctx, size_t bytes, void** dptr);
@@ -99,7 +111,10 @@ int pvs_pca_destroy(pvs_ctx* ctx, pvs_pca* p);
  * pca may be NULL.  out: float32 [n_images][K*D] (k-major, flatten=True layout).  An image with zero
  * descriptors yields a zero row (the reference aborts the batch, vlad.py:92-93 -- fenced quirk).
  * out_labels (optional): int32 [total descriptors], the KMeans.predict labels (vlad.py:95).
- * out_inv_norm (optional, _dev only): float32 [n_images], 1/||row||_2 (1 for zero rows) for the cosine step. */
+ * out_inv_norm (optional, _dev only): float32 [n_images], 1/||row||_2 (1 for zero rows) for the cosine step.
+ * The host forms validate the offsets (offsets[0] == 0, non-decreasing).  pvs_vlad_encode_dev never synchronises, so it
+ * cannot: d_offsets[0] == 0, non-decreasing, d_offsets[n_images] == total_desc are PRECONDITIONS of that entry point
+ * (pvs_fisher_encode_dev copies the offsets to the host for batching and does check them). */
 int pvs_vlad_encode(pvs_ctx* ctx, const pvs_codebook* cb, const pvs_pca* pca, const void* desc,
                     int desc_kind, const int64_t* offsets, int64_t n_images, const pvs_norm_params* prm,
                     float* out, int32_t* out_labels);

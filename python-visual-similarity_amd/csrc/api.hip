@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <memory>
 
 #include "common.hpp"
 
@@ -93,23 +94,21 @@ PVS_EXPORT int pvs_init(int device_id, void* stream, pvs_ctx** out) {
     PVS_FAIL(PVS_ERR_NO_DEVICE, "no HIP device visible: this engine has no CPU fallback");
   if (device_id < 0 || device_id >= n) PVS_FAIL(PVS_ERR_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
   PVS_HIP(hipSetDevice(device_id));
-  pvs_ctx* c = new pvs_ctx();
+  hipDeviceProp_t prop;
+  PVS_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    PVS_FAIL(PVS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id,
+             prop.gcnArchName);
+  std::unique_ptr<pvs_ctx> c(new pvs_ctx());
   c->device = device_id;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (stream) {
     c->stream = static_cast<hipStream_t>(stream);
   } else {
     PVS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->owns_stream = true;
   }
-  hipDeviceProp_t prop;
-  PVS_HIP(hipGetDeviceProperties(&prop, device_id));
-  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-    delete c;
-    PVS_FAIL(PVS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id,
-             prop.gcnArchName);
-  }
-  *out = c;
+  *out = c.release();
   return PVS_OK;
 }
 
@@ -120,6 +119,8 @@ PVS_EXPORT int pvs_destroy(pvs_ctx* ctx) {
   drain_timers(ctx);
   for (int i = 0; i < pvs_ctx::NWS; ++i)
     if (ctx->ws[i]) hipFree(ctx->ws[i]);
+  for (auto& p : ctx->gemm_plan)
+    if (p.d_tiles) hipFree(p.d_tiles);
   if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return PVS_OK;
@@ -139,6 +140,22 @@ PVS_EXPORT int pvs_device_name(pvs_ctx* ctx, char* buf, size_t buflen) {
   hipDeviceProp_t prop;
   PVS_HIP(hipGetDeviceProperties(&prop, ctx->device));
   snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_set_option(pvs_ctx* ctx, int option, int value) {
+  PVS_NEED(ctx, "ctx");
+  if (option < 0 || option >= PVS_OPT_COUNT_) PVS_FAIL(PVS_ERR_INVALID, "unknown option %d", option);
+  const int hi = option == PVS_OPT_VLAD_PATH ? 3 : 1;
+  if (value < 0 || value > hi) PVS_FAIL(PVS_ERR_INVALID, "option %d: value %d out of range 0..%d", option, value, hi);
+  ctx->opt[option] = value;
+  return PVS_OK;
+}
+PVS_EXPORT int pvs_get_option(pvs_ctx* ctx, int option, int* value) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(value, "value");
+  if (option < 0 || option >= PVS_OPT_COUNT_) PVS_FAIL(PVS_ERR_INVALID, "unknown option %d", option);
+  *value = ctx->opt[option];
   return PVS_OK;
 }
 

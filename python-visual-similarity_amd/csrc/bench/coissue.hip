@@ -96,5 +96,17 @@ int main() {
   run<3, 6, 4>("split waves: MFMA | cmp/cndmask", 512, it);
   run<2, 6, 2>("same wave MFMA + iadd", 256, it);
   run<2, 6, 1>("same wave MFMA + med3", 256, it);
+  // round 2: the same-wave interleave (1 MFMA : NV VALU) for every op class, one and two waves per SIMD, and fewer fillers
+  run<2, 6, 0>("same wave MFMA + 6 fma", 256, it);
+  run<2, 6, 0>("same wave MFMA + 6 fma", 512, it);
+  run<2, 3, 0>("same wave MFMA + 3 fma", 256, it);
+  run<2, 3, 0>("same wave MFMA + 3 fma", 512, it);
+  run<2, 6, 4>("same wave MFMA + 6 (cmp,cndmask,add)", 256, it);
+  run<2, 2, 4>("same wave MFMA + 2 (cmp,cndmask,add)", 256, it);
+  run<2, 2, 4>("same wave MFMA + 2 (cmp,cndmask,add)", 512, it);
+  run<2, 6, 3>("same wave MFMA + 6 (cvt,cvt,add)", 256, it);
+  run<2, 6, 1>("same wave MFMA + med3", 512, it);
+  run<1, 6, 0>("VALU only fma", 512, it);
+  run<1, 6, 4>("VALU only cmp+cndmask+add", 512, it);
   return 0;
 }

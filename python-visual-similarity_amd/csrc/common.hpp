@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "../../include/pvsim.h"
@@ -62,6 +63,18 @@ struct pvs_ctx {
   static constexpr int NWS = 7;
   void* ws[NWS] = {};
   size_t ws_bytes[NWS] = {};
+  // cached tile lists of the similarity GEMM, one per GEMM model (cosine.hip): a context is one device + one stream, so the
+  // list a launch reads can only be replaced by work queued behind it on the same stream
+  struct GemmPlanSlot {
+    int key[4] = {-1, -1, -1, -1};   // tiles_m, tiles_n, symmetric, resident workgroup slots
+    int n_main = 0, n_tail = 0, splitk = 1;
+    void* d_tiles = nullptr;
+    size_t cap = 0;
+  } gemm_plan[3];
+  // dynamic-LDS limits already raised on this context's device: kernel -> bytes
+  std::map<const void*, int> lds_attr;
+  // behaviour switches (pvs_set_option); defaults = the product path
+  int opt[PVS_OPT_COUNT_] = {1, 0, 0};
   // timers
   bool timers_on = false;
   std::vector<pvs::TimerRec> pending;
@@ -105,12 +118,38 @@ namespace pvs {
 
 int ws_reserve(pvs_ctx* ctx, int which, size_t bytes, void** out);
 
+// raise a kernel's dynamic-LDS limit once per context (and again when a launch needs more)
+inline int ensure_lds(pvs_ctx* ctx, const void* fn, size_t bytes) {
+  auto it = ctx->lds_attr.find(fn);
+  if (it == ctx->lds_attr.end() || it->second < (int)bytes) {
+    PVS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->lds_attr[fn] = (int)bytes;
+  }
+  return PVS_OK;
+}
+
 struct ScopedTimer {
   pvs_ctx* ctx;
   int slot;
   hipEvent_t a = nullptr, b = nullptr;
   ScopedTimer(pvs_ctx* c, int s) : ctx(c), slot(s) {
     if (ctx->timers_on) {
+      // a long-running caller that never reads the timers must not pile up events: fold in the finished ones (in order,
+      // non-blocking) once a few hundred are pending
+      if (ctx->pending.size() >= 512) {
+        size_t done = 0;
+        while (done < ctx->pending.size() && hipEventQuery(ctx->pending[done].b) == hipSuccess) {
+          float ms = 0.f;
+          if (hipEventElapsedTime(&ms, ctx->pending[done].a, ctx->pending[done].b) == hipSuccess) {
+            ctx->t_total[ctx->pending[done].slot] += ms;
+            ctx->t_count[ctx->pending[done].slot] += 1;
+          }
+          (void)hipEventDestroy(ctx->pending[done].a);
+          (void)hipEventDestroy(ctx->pending[done].b);
+          ++done;
+        }
+        ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + done);
+      }
       (void)hipEventCreate(&a);
       (void)hipEventCreate(&b);
       (void)hipEventRecord(a, ctx->stream);

@@ -64,24 +64,12 @@ template <> struct GemmModel<0> { using Cfg = GemmMain; static constexpr bool F1
 template <> struct GemmModel<1> { using Cfg = GemmHalf; static constexpr bool F16 = true, TWO = false; static constexpr int BM = 256, WN = 4, PER_CU = 1; };
 template <> struct GemmModel<2> { using Cfg = GemmPre; static constexpr bool F16 = true, TWO = true; static constexpr int BM = 128, WN = 2, PER_CU = 2; };
 
-struct GemmPlanKey {
-  int tiles_m = -1, tiles_n = -1, symm = -1, slots = -1;
-  bool operator==(const GemmPlanKey& o) const {
-    return tiles_m == o.tiles_m && tiles_n == o.tiles_n && symm == o.symm && slots == o.slots;
-  }
-};
-struct GemmPlan {
-  GemmPlanKey key;
-  int n_main = 0, n_tail = 0, splitk = 1;
-  GemmTile* d_tiles = nullptr;
-  size_t cap = 0;
-};
-static GemmPlan g_plan[3];  // one cached plan per GEMM model (see GemmModel) per process
+using GemmPlan = pvs_ctx::GemmPlanSlot;   // lives in the context (one device, one stream): never shared between contexts
 
 static int build_plan(pvs_ctx* ctx, int which, int tiles_m, int tiles_n, bool symm, int slots, GemmPlan** out) {
-  GemmPlan& P = g_plan[which];
-  const GemmPlanKey key{tiles_m, tiles_n, symm ? 1 : 0, slots};
-  if (!(P.key == key)) {
+  GemmPlan& P = ctx->gemm_plan[which];
+  const int key[4] = {tiles_m, tiles_n, symm ? 1 : 0, slots};
+  if (memcmp(P.key, key, sizeof(key)) != 0) {
     std::vector<GemmTile> t;
     if (symm) {
       const int TS = (tiles_m + 7) / 8;
@@ -124,12 +112,16 @@ static int build_plan(pvs_ctx* ctx, int which, int tiles_m, int tiles_n, bool sy
     if (P.cap < t.size()) {
       PVS_HIP(hipStreamSynchronize(ctx->stream));
       if (P.d_tiles) PVS_HIP(hipFree(P.d_tiles));
-      P.cap = t.size() + t.size() / 4 + 64;
-      PVS_HIP(hipMalloc(reinterpret_cast<void**>(&P.d_tiles), P.cap * sizeof(GemmTile)));
+      P.d_tiles = nullptr;
+      P.cap = 0;
+      P.key[0] = -1;
+      const size_t cap = t.size() + t.size() / 4 + 64;
+      PVS_HIP(hipMalloc(&P.d_tiles, cap * sizeof(GemmTile)));
+      P.cap = cap;
     }
     PVS_HIP(hipMemcpyAsync(P.d_tiles, t.data(), t.size() * sizeof(GemmTile), hipMemcpyHostToDevice, ctx->stream));
     PVS_HIP(hipStreamSynchronize(ctx->stream));  // `t` is pageable host memory going out of scope
-    P.key = key;
+    memcpy(P.key, key, sizeof(key));
   }
   *out = &P;
   return PVS_OK;
@@ -147,13 +139,9 @@ static int launch_gemm_mfma(pvs_ctx* ctx, GemmArgs g, const GemmPlan& plan) {
   auto kfull = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_FULL, false, F16, TWO, ILV, DUAL>;
   auto kpart = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_PARTIAL, false, F16, TWO, ILV, DUAL>;
   auto kred = gemm_mfma_kernel<BM, BM, WM, WN, 2, SYMM, 2, GEMM_MODE_REDUCE, false, F16, TWO, ILV, DUAL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    for (const void* k : {reinterpret_cast<const void*>(kfull), reinterpret_cast<const void*>(kpart),
-                          reinterpret_cast<const void*>(kred)})
-      PVS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-    attr_set = true;
-  }
+  for (const void* k : {reinterpret_cast<const void*>(kfull), reinterpret_cast<const void*>(kpart),
+                        reinterpret_cast<const void*>(kred)})
+    PVS_TRY(ensure_lds(ctx, k, Cfg::LDS_BYTES));
   if (plan.n_main > 0) {
     g.tile_base = 0;
     hipLaunchKernelGGL(kfull, dim3((unsigned)plan.n_main), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
@@ -198,7 +186,7 @@ static int cosine_mfma(pvs_ctx* ctx, const void* A, int64_t M, const void* B, in
   GemmArgs g{};
   g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = ld ? ld : L; g.ldb = ld ? ld : L; g.inva = inva; g.invb = invb;
   g.accumulate = accumulate;
-  g.out = out; g.ldo = ldo; g.out_t = out_t; g.ldt = ldt; g.tiles = plan->d_tiles; g.splitk = 1;
+  g.out = out; g.ldo = ldo; g.out_t = out_t; g.ldt = ldt; g.tiles = static_cast<const GemmTile*>(plan->d_tiles); g.splitk = 1;
   PVS_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(const_cast<float**>(&g.zero16)), HIP_SYMBOL(g_zero16)));
   if (symm) return launch_gemm_mfma<true, MODEL>(ctx, g, *plan);
   if constexpr (MODEL == 0) {

@@ -613,11 +613,7 @@ constexpr size_t MM_LDS = (size_t)(2 * 256 * F64_KCP + 2 * 128 * F64_KCP + 256 +
 template <bool RAW, int PM, int NM, bool OUT64>
 static int launch_moments(pvs_ctx* ctx, dim3 grid, const MomMArgs& m) {
   auto k = fisher_moments_mfma_kernel<RAW, PM, NM, OUT64>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MM_LDS));
-    attr_set = true;
-  }
+  PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(k), MM_LDS));
   hipLaunchKernelGGL(k, grid, dim3(MM_THREADS), MM_LDS, ctx->stream, m);
   return PVS_OK;
 }
@@ -824,11 +820,7 @@ static int posterior_mfma_on(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int
                      g->K, g->D, tab2);
   PostMArgs a{x, total, g->D, ld, g->K, tab2, g->d_const, d_resp, d_lse};
   constexpr size_t lds = (size_t)(2 * PM_ROWS * F64_KCP + 2 * PM_COLS * F64_KCP + PM_ROWS * 4) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_posterior_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(gmm_posterior_mfma_kernel), lds));
   ScopedTimer tm(ctx, T_FPOST);
   hipLaunchKernelGGL(gmm_posterior_mfma_kernel, dim3((unsigned)((total + PM_ROWS - 1) / PM_ROWS)), dim3(PM_THREADS), lds, ctx->stream, a);
   PVS_HIP(hipGetLastError());
@@ -978,6 +970,12 @@ int launch_fisher(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int kind, 
   std::vector<int64_t> off((size_t)n_images + 1);
   PVS_HIP(hipMemcpyAsync(off.data(), d_offsets, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
   PVS_HIP(hipStreamSynchronize(ctx->stream));
+  // the offsets index workspaces sized from `total`: a bad table is an argument error, never an out-of-bounds access
+  if (off[0] != 0) PVS_FAIL(PVS_ERR_INVALID, "offsets[0] must be 0 (got %lld)", (long long)off[0]);
+  for (int64_t i = 0; i < n_images; ++i)
+    if (off[i + 1] < off[i]) PVS_FAIL(PVS_ERR_INVALID, "offsets must be non-decreasing (image %lld)", (long long)i);
+  if (off[n_images] != total)
+    PVS_FAIL(PVS_ERR_INVALID, "offsets[n_images] = %lld does not match total_desc = %lld", (long long)off[n_images], (long long)total);
   const size_t per_img = 4096;
   const size_t budget = (size_t)3 << 30;
   const int bt = D <= 128 ? 128 : 256;

@@ -276,7 +276,7 @@ static int launch_topk_impl(pvs_ctx* ctx, const TopkArgs& a) {
   if (a.nq > 0x7fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "top-k: too many query rows for one launch");
   if (a.col_offset + a.ncols > 0xfffffffeLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "top-k: column index exceeds 32 bits");
   ScopedTimer tm(ctx, T_TOPK);
-  if (a.k <= TKS_KMAX && a.n_lists == 0 && a.out_off == 0 && a.out_ld == a.k && getenv("PVS_TOPK_SELECT_ONLY") == nullptr)
+  if (a.k <= TKS_KMAX && a.n_lists == 0 && a.out_off == 0 && a.out_ld == a.k && !ctx->opt[PVS_OPT_TOPK_SELECT_ONLY])
     hipLaunchKernelGGL(topk_small_kernel, dim3((unsigned)a.nq), dim3(TK_THREADS), 0, ctx->stream, a);
   else
     hipLaunchKernelGGL(topk_kernel, dim3((unsigned)a.nq), dim3(TK_THREADS), 0, ctx->stream, a);

@@ -10,8 +10,6 @@
 // descriptor rows streamed HBM -> registers.  K2/K3 is HBM/latency bound: per image a stable counting
 // sort of the labels in LDS, then one lane-group per cluster sums its descriptors IN DESCRIPTOR ORDER
 // (bit-identical to the reference's loop given equal labels; no float atomics, run-to-run reproducible).
-#include <cstdlib>
-
 #include "common.hpp"
 #include "desc_load.hpp"
 
@@ -556,7 +554,7 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
   const int grid = (int)(nblocks < ctx->num_cu ? nblocks : ctx->num_cu);
   ScopedTimer tm(ctx, T_ASSIGN);
   // ---- prefilter pass (fp16 MFMA) when the whole table has an fp16 copy; it leaves the near ties to the exact kernel
-  const bool pre = cb->d_c16 != nullptr && total >= 4096 && getenv("PVS_ASSIGN_EXACT_ONLY") == nullptr;
+  const bool pre = cb->d_c16 != nullptr && total >= 4096 && ctx->opt[PVS_OPT_ASSIGN_PREFILTER] != 0;
   if (pre) {
     const int64_t cap = (nblocks + grid - 1) / grid * ASSIGN_ROWS;   // a workgroup can list at most what it processes
     char* ws = nullptr;
@@ -1086,9 +1084,9 @@ int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_de
                    ((reinterpret_cast<uintptr_t>(d_out) % 16) == 0);
   const size_t lds = (size_t)(AGG_WAVES * cb->K + cb->K + 1) * 4 + (size_t)cb->K * 4 + (size_t)AGG_WAVES * 4 + (size_t)AGG_CHUNK * 2 + 16;
   ScopedTimer tm(ctx, T_AGGREGATE);
-  // accumulators in LDS, rows streamed in descriptor order (see vlad_stream_kernel): experimental, PVS_AGG_STREAM=1 selects it
+  // accumulators in LDS, rows streamed in descriptor order (see vlad_stream_kernel): opt-in: pvs_set_option(PVS_OPT_VLAD_PATH, 2)
   const size_t lds_s = (size_t)cb->K * cb->D * 4 + (size_t)(ST_WAVES * ST_UNITS + ST_UNITS + 1) * 4 + (size_t)cb->K * 4 + (size_t)AGG_CHUNK * 4 + 16;
-  static const bool stream_ok = [] { const char* e = getenv("PVS_AGG_STREAM"); return e != nullptr && atoi(e) != 0; }();
+  const bool stream_ok = ctx->opt[PVS_OPT_VLAD_PATH] == 2;
   if (stream_ok && vec && cb->D <= 128 && (size_t)cb->K * cb->D <= 32768 && lds_s <= 160 * 1024 - 512 &&
       (reinterpret_cast<uintptr_t>(cb->d_cent) % 16) == 0) {
     switch (kind) {

@@ -20,6 +20,8 @@ _EXC = {PVS_ERR_INVALID: ValueError, PVS_ERR_NO_DEVICE: RuntimeError, PVS_ERR_OO
         PVS_ERR_UNSUPPORTED: NotImplementedError, PVS_ERR_DIM: RuntimeError}
 
 DESC_F32, DESC_F32_ROOTSIFT, DESC_U8_ROOTSIFT = 0, 1, 2
+OPT_ASSIGN_PREFILTER, OPT_VLAD_PATH, OPT_TOPK_SELECT_ONLY = 0, 1, 2      # pvs_option
+VLAD_PATH_AUTO, VLAD_PATH_GATHER, VLAD_PATH_STREAM, VLAD_PATH_FUSED = 0, 1, 2, 3
 TIMER_NAMES = ("assign", "aggregate", "cosine_gemm", "topk", "fisher_posterior", "fisher_moments", "misc", "rescore")
 
 
@@ -41,6 +43,8 @@ SIGNATURES = {
     "pvs_sync": [_vp],
     "pvs_stream": [_vp],
     "pvs_device_name": [_vp, C.c_char_p, _sz],
+    "pvs_set_option": [_vp, _int, _int],
+    "pvs_get_option": [_vp, _int, C.POINTER(C.c_int)],
     "pvs_malloc": [_vp, _sz, _pp],
     "pvs_free": [_vp, _vp],
     "pvs_memcpy_h2d": [_vp, _vp, _vp, _sz],

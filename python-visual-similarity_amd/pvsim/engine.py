@@ -153,6 +153,29 @@ class Context:
     def stream(self) -> int:
         return int(_ffi.lib().pvs_stream(self.handle) or 0)
 
+    def set_option(self, option: int, value: int) -> None:
+        """pvs_set_option: pins one of several implementations that must agree bit for bit (tests, benchmarks)."""
+        check(_ffi.lib().pvs_set_option(self.handle, int(option), int(value)))
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int()
+        check(_ffi.lib().pvs_get_option(self.handle, int(option), C.byref(v)))
+        return int(v.value)
+
+    def option(self, option: int, value: int):
+        """Context manager: `with ctx.option(OPT_ASSIGN_PREFILTER, 0): ...` restores the previous value on exit."""
+        ctx = self
+
+        class _Scoped:
+            def __enter__(self_inner):
+                self_inner.old = ctx.get_option(option)
+                ctx.set_option(option, value)
+
+            def __exit__(self_inner, *exc):
+                ctx.set_option(option, self_inner.old)
+
+        return _Scoped()
+
     def device_name(self) -> str:
         buf = C.create_string_buffer(256)
         check(_ffi.lib().pvs_device_name(self.handle, buf, 256))

@@ -12,7 +12,7 @@ import pytest
 
 import pvsim_oracle as orc
 from conftest import load_golden
-from pvsim import synth, pack_descriptors
+from pvsim import synth, pack_descriptors, _ffi
 from pvsim.engine import DESC_F32, DESC_F32_ROOTSIFT, DESC_U8_ROOTSIFT
 
 pytestmark = pytest.mark.gpu
@@ -741,9 +741,8 @@ def test_prefiltered_assignment_equals_the_exact_kernel(gpu_ctx, tables, kind, m
     else:
         x = raw.astype(np.uint8)
     off = np.array([0, len(x)], np.int64)
-    monkeypatch.setenv("PVS_ASSIGN_EXACT_ONLY", "1")
-    _, exact = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
-    monkeypatch.delenv("PVS_ASSIGN_EXACT_ONLY")
+    with gpu_ctx.option(_ffi.OPT_ASSIGN_PREFILTER, 0):
+        _, exact = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
     _, pre = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
     assert np.array_equal(exact, pre), np.argwhere(exact != pre)[:10]
     assert not np.any(pre == 200)                    # never the later duplicate
@@ -759,9 +758,8 @@ def test_prefiltered_assignment_odd_shapes(gpu_ctx, K, D, monkeypatch):
     x[50:100] *= 1e-4
     cb = gpu_ctx.codebook(C)
     off = np.array([0, len(x)], np.int64)
-    monkeypatch.setenv("PVS_ASSIGN_EXACT_ONLY", "1")
-    _, exact = gpu_ctx.vlad_encode(cb, x, off, DESC_F32, return_labels=True)
-    monkeypatch.delenv("PVS_ASSIGN_EXACT_ONLY")
+    with gpu_ctx.option(_ffi.OPT_ASSIGN_PREFILTER, 0):
+        _, exact = gpu_ctx.vlad_encode(cb, x, off, DESC_F32, return_labels=True)
     _, pre = gpu_ctx.vlad_encode(cb, x, off, DESC_F32, return_labels=True)
     assert np.array_equal(exact, pre), np.argwhere(exact != pre)[:10]
     assert np.array_equal(pre, orc.kmeans_predict(x, C)) or np.mean(pre != orc.kmeans_predict(x, C)) < 1e-3
@@ -929,10 +927,7 @@ def test_small_k_kernel_equals_the_radix_select(gpu_ctx, nq, N, k, monkeypatch):
     panels = [(0, N // 2), (N // 2, N)] if N > 20 else [(0, N)]
     out = []
     for select_only in (True, False):
-        if select_only:
-            monkeypatch.setenv("PVS_TOPK_SELECT_ONLY", "1")
-        else:
-            monkeypatch.delenv("PVS_TOPK_SELECT_ONLY", raising=False)
+        gpu_ctx.set_option(_ffi.OPT_TOPK_SELECT_ONLY, int(select_only))
         idx = torch.full((nq, k), -9, dtype=torch.int64, device=dev)
         val = torch.full((nq, k), -9.0, dtype=torch.float32, device=dev)
         for p, (c0, c1) in enumerate(panels):                  # second panel merges into the running lists
@@ -941,6 +936,7 @@ def test_small_k_kernel_equals_the_radix_select(gpu_ctx, nq, N, k, monkeypatch):
             gpu_ctx.topk_dev(t.data_ptr(), nq, c1 - c0, c1 - c0, k, c0, p > 0, idx.data_ptr(), val.data_ptr())
             gpu_ctx.sync()
         out.append((idx.cpu().numpy(), val.cpu().numpy()))
+    gpu_ctx.set_option(_ffi.OPT_TOPK_SELECT_ONLY, 0)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
 
