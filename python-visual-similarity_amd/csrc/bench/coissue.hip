@@ -15,6 +15,14 @@ __device__ __forceinline__ float vop(float x, float seed) {
   if (OP == 1) return __builtin_amdgcn_fmed3f(x, seed, 3.f);
   if (OP == 2) return __int_as_float(__float_as_int(x) + 12345);
   if (OP == 3) return (float)(_Float16)x + 0.f;      // cvt + cvt
+  if (OP == 5) return __builtin_fmaxf(x, seed);       // v_max_f32
+  if (OP == 6) return __int_as_float((__float_as_int(x) & ~31) | (__float_as_int(seed) & 31) | 3);   // v_and_or_b32 class
+  if (OP == 7) {                                       // the packed-key scan step: and_or, max, med3
+    const float key = __int_as_float((__float_as_int(x) & ~31) | 5);
+    const float b = __builtin_fmaxf(seed, key);
+    return __builtin_amdgcn_fmed3f(seed, b, key);
+  }
+  if (OP == 8) return x < seed ? seed : x;             // cmp + cndmask
   return x < seed ? seed : x + 1.f;                   // cmp + cndmask + add
 }
 template <int MODE, int NV, int OP>
@@ -106,6 +114,20 @@ int main() {
   run<2, 2, 4>("same wave MFMA + 2 (cmp,cndmask,add)", 512, it);
   run<2, 6, 3>("same wave MFMA + 6 (cvt,cvt,add)", 256, it);
   run<2, 6, 1>("same wave MFMA + med3", 512, it);
+  run<1, 6, 5>("VALU only max", 256, it);
+  run<3, 6, 5>("split waves: MFMA | max", 512, it);
+  run<2, 6, 5>("same wave MFMA + 6 max", 256, it);
+  run<2, 6, 5>("same wave MFMA + 6 max", 512, it);
+  run<1, 6, 6>("VALU only and_or", 256, it);
+  run<2, 6, 6>("same wave MFMA + 6 and_or", 256, it);
+  run<2, 6, 6>("same wave MFMA + 6 and_or", 512, it);
+  run<1, 2, 7>("VALU only 2 x (and_or,max,med3)", 256, it);
+  run<2, 2, 7>("same wave MFMA + 2 x (and_or,max,med3)", 256, it);
+  run<2, 2, 7>("same wave MFMA + 2 x (and_or,max,med3)", 512, it);
+  run<2, 1, 7>("same wave MFMA + 1 x (and_or,max,med3)", 512, it);
+  run<1, 3, 8>("VALU only 3 x (cmp,cndmask)", 256, it);
+  run<2, 3, 8>("same wave MFMA + 3 x (cmp,cndmask)", 256, it);
+  run<2, 3, 8>("same wave MFMA + 3 x (cmp,cndmask)", 512, it);
   run<1, 6, 0>("VALU only fma", 512, it);
   run<1, 6, 4>("VALU only cmp+cndmask+add", 512, it);
   return 0;
