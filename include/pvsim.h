@@ -177,6 +177,12 @@ int pvs_cosine_topk_f16_dev(pvs_ctx* ctx, const void* d_Q16, int64_t nq, const v
                             int64_t* d_idx, float* d_val);
 int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L, int k,
                     int64_t* out_idx, float* out_val);
+/* float64 operands (Fisher encodings): the reference scores and ranks in float64 unless BOTH operands are float32
+ * (pyvisim/_utils.py:312-330 -> sklearn cosine_similarity; eval.py:37-43,75-80,131-132 argsort that array).  Host pointers;
+ * out_val float64 [nq][k], same order as the fp32 entry points (score descending, index ascending, NaN last).
+ * k <= 4096 when N > 8192 (PVS_ERR_UNSUPPORTED otherwise). */
+int pvs_cosine_topk_f64(pvs_ctx* ctx, const double* Q, int64_t nq, const double* DB, int64_t N, int64_t L, int k,
+                        int64_t* out_idx, double* out_val);
 /* The same lists as pvs_cosine_topk_dev(col_offset 0, merge 0) -- bit-identical indices AND scores -- computed faster:
  * all pairs are scored with fp16 operands under a proven error bound, the columns within twice that bound of each query's
  * approximate k-th best are re-scored with the exact fp32 recurrence of the f32 GEMM kernel, and those are ranked.

@@ -121,6 +121,7 @@ PVS_EXPORT int pvs_destroy(pvs_ctx* ctx) {
     if (ctx->ws[i]) hipFree(ctx->ws[i]);
   for (auto& p : ctx->gemm_plan)
     if (p.d_tiles) hipFree(p.d_tiles);
+  if (ctx->d_queue) hipFree(ctx->d_queue);
   if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return PVS_OK;
@@ -247,6 +248,39 @@ PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, 
     if (hipMalloc(&cb->d_c16, h16.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
     else if (hipMemcpyAsync(cb->d_c16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
     if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;   // h16 goes out of scope
+    // tables of the fused encode (vlad_fused.hip): natural dim order, and -|c|^2/2 as three exact fp16 pieces
+    if (st == PVS_OK && cb->K_pad == 256 && D == 128) {
+      std::vector<_Float16> n16((size_t)2 * 256 * 128, (_Float16)0.f), pk((size_t)256 * 4, (_Float16)0.f);
+      float amaxa = 0.f;
+      for (int k = 0; k < K; ++k) amaxa = std::max(amaxa, std::fabs(std::ldexp(-0.5f * cn[k], cb->c16_shift)));
+      int ea = 0;
+      (void)std::frexp(amaxa, &ea);
+      cb->cn_e1 = ea - 13;
+      for (int k = 0; k < 256; ++k) {
+        if (k < K) {
+          for (int d = 0; d < 128; ++d) {
+            const float v = centroids[(size_t)k * D + d] * sc;
+            const _Float16 hi = (_Float16)v;
+            n16[(size_t)k * 128 + d] = hi;
+            n16[(size_t)256 * 128 + (size_t)k * 128 + d] = (_Float16)(v - (float)hi);
+          }
+          const float av = std::ldexp(-0.5f * cn[k], cb->c16_shift - cb->cn_e1);   // exact: powers of two
+          const _Float16 p1 = (_Float16)av;
+          const float r1 = av - (float)p1;
+          const _Float16 p2 = (_Float16)r1;
+          const float r2 = r1 - (float)p2;
+          pk[(size_t)k * 4 + 0] = p1; pk[(size_t)k * 4 + 1] = p2; pk[(size_t)k * 4 + 2] = (_Float16)r2;
+        } else {
+          pk[(size_t)k * 4 + 0] = (_Float16)(-65504.f);   // below every real score of a row the prefilter takes
+        }
+      }
+      if (std::isfinite(amaxa) && amaxa > 0.f) {
+        if (hipMalloc(&cb->d_c16n, n16.size() * 2) != hipSuccess || hipMalloc(&cb->d_cnk, pk.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
+        else if (hipMemcpyAsync(cb->d_c16n, n16.data(), n16.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                 hipMemcpyAsync(cb->d_cnk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
+        if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
+      }
+    }
   }
   if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
   if (st != PVS_OK) {
@@ -264,6 +298,8 @@ PVS_EXPORT int pvs_codebook_destroy(pvs_ctx* ctx, pvs_codebook* cb) {
   if (cb->d_cpad) hipFree(cb->d_cpad);
   if (cb->d_cnorm) hipFree(cb->d_cnorm);
   if (cb->d_c16) hipFree(cb->d_c16);
+  if (cb->d_c16n) hipFree(cb->d_c16n);
+  if (cb->d_cnk) hipFree(cb->d_cnk);
   delete cb;
   return PVS_OK;
 }
@@ -426,6 +462,13 @@ PVS_EXPORT int pvs_vlad_encode_dev(pvs_ctx* ctx, const pvs_codebook* cb, const p
   int kind = desc_kind, ld = 0;
   const void* x = d_desc;
   PVS_TRY(project_if_needed(ctx, pca, cb->D, x, kind, total_desc, ld));
+  // one pass over the descriptors when the table shape qualifies (vlad_fused.hip); PVS_OPT_VLAD_PATH pins a path
+  const int path = ctx->opt[PVS_OPT_VLAD_PATH];
+  const bool fused_ok = ctx->opt[PVS_OPT_ASSIGN_PREFILTER] != 0 && vlad_fused_eligible(cb, x, kind, ld, d_out);
+  if (path == 3 && !fused_ok)
+    PVS_FAIL(PVS_ERR_UNSUPPORTED, "fused VLAD encode needs D = 128, 128 < K <= 256, aligned rows and the fp16 prefilter tables");
+  if ((path == 0 || path == 3) && fused_ok)
+    return launch_vlad_fused(ctx, cb, x, kind, ld, d_offsets, n_images, *prm, d_out, d_labels, d_inv_norm);
   int32_t* labels = d_labels;
   if (!labels)
     PVS_TRY(ws_reserve(ctx, 1, (size_t)std::max<int64_t>(total_desc, 1) * sizeof(int32_t),
@@ -794,6 +837,45 @@ PVS_EXPORT int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const f
   PVS_HIP(hipMemcpyAsync(out_idx, d_idx, (size_t)nq * k * 8, hipMemcpyDeviceToHost, ctx->stream));
   PVS_HIP(hipMemcpyAsync(out_val, d_val, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
   PVS_HIP(hipStreamSynchronize(ctx->stream));
+  return PVS_OK;
+}
+
+
+// float64 scores + ranking (the reference's dtype rule for Fisher encodings); query rows go through in panels of <= 256 MiB
+PVS_EXPORT int pvs_cosine_topk_f64(pvs_ctx* ctx, const double* Q, int64_t nq, const double* DB, int64_t N, int64_t L, int k,
+                                   int64_t* out_idx, double* out_val) {
+  PVS_NEED(ctx, "ctx");
+  if (nq <= 0) return PVS_OK;
+  if (L <= 1) PVS_FAIL(PVS_ERR_INVALID, "Cosine similarity requires at least 2 features. Got %lld features.", (long long)L);
+  PVS_NEED(Q, "Q");
+  PVS_NEED(DB, "DB");
+  PVS_NEED(out_idx, "idx");
+  PVS_NEED(out_val, "val");
+  if (N <= 0) PVS_FAIL(PVS_ERR_INVALID, "empty database");
+  if (k < 1 || k > N) PVS_FAIL(PVS_ERR_INVALID, "k = %d out of range 1..%lld", k, (long long)N);
+  PVS_HIP(hipSetDevice(ctx->device));
+  const int64_t QT = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)32 << 20) / N));
+  const size_t db_bytes = ((size_t)N * L * 8 + 255) / 256 * 256, q_bytes = ((size_t)QT * L * 8 + 255) / 256 * 256;
+  char* d_in = nullptr;
+  char* d_s = nullptr;
+  PVS_TRY(ws_reserve(ctx, 0, db_bytes + q_bytes, reinterpret_cast<void**>(&d_in)));
+  const size_t panel_b = ((size_t)QT * N * 8 + 255) / 256 * 256, idx_b = ((size_t)QT * k * 8 + 255) / 256 * 256;
+  PVS_TRY(ws_reserve(ctx, 2, panel_b + 2 * idx_b, reinterpret_cast<void**>(&d_s)));
+  double* d_db = reinterpret_cast<double*>(d_in);
+  double* d_q = reinterpret_cast<double*>(d_in + db_bytes);
+  double* panel = reinterpret_cast<double*>(d_s);
+  int64_t* d_idx = reinterpret_cast<int64_t*>(d_s + panel_b);
+  double* d_val = reinterpret_cast<double*>(d_s + panel_b + idx_b);
+  PVS_HIP(hipMemcpyAsync(d_db, DB, (size_t)N * L * 8, hipMemcpyHostToDevice, ctx->stream));
+  for (int64_t q0 = 0; q0 < nq; q0 += QT) {
+    const int64_t qn = std::min(QT, nq - q0);
+    PVS_HIP(hipMemcpyAsync(d_q, Q + q0 * L, (size_t)qn * L * 8, hipMemcpyHostToDevice, ctx->stream));
+    PVS_TRY(launch_cosine_f64(ctx, d_q, qn, d_db, N, L, panel));
+    PVS_TRY(launch_rank_f64(ctx, panel, qn, N, N, k, d_idx, d_val));
+    PVS_HIP(hipMemcpyAsync(out_idx + q0 * k, d_idx, (size_t)qn * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PVS_HIP(hipMemcpyAsync(out_val + q0 * k, d_val, (size_t)qn * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PVS_HIP(hipStreamSynchronize(ctx->stream));   // d_q and the panel are reused by the next batch
+  }
   return PVS_OK;
 }
 

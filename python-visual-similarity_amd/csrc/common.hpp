@@ -75,6 +75,7 @@ struct pvs_ctx {
   std::map<const void*, int> lds_attr;
   // behaviour switches (pvs_set_option); defaults = the product path
   int opt[PVS_OPT_COUNT_] = {1, 0, 0};
+  unsigned int* d_queue = nullptr;   // image queue head of the fused encode (persistent workgroups)
   // timers
   bool timers_on = false;
   std::vector<pvs::TimerRec> pending;
@@ -93,6 +94,10 @@ struct pvs_codebook {
   int D_pad16 = 0;           // multiple of 16
   int c16_shift = 0;         // the largest |c| 2^shift lies in [2^12, 2^13)
   float cmax = 0.f;          // max_k ||c_k||_2
+  // tables of the fused encode (vlad_fused.hip; K_pad == 256 and D == 128 only)
+  void* d_c16n = nullptr;    // [2][256][128] _Float16: the same hi | lo values in natural dim order, zero rows for padded clusters
+  void* d_cnk = nullptr;     // [256][4] _Float16: three pieces of -|c|^2/2 2^(c16_shift - cn_e1) (padded clusters: -65504, 0, 0), 0
+  int cn_e1 = 0;             // the largest |c|^2/2 2^(c16_shift - cn_e1) lies in [2^12, 2^13)
 };
 
 struct pvs_gmm {
@@ -169,6 +174,9 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
 int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int ld,
                           const int64_t* d_offsets, int64_t n_images, const int32_t* d_labels,
                           const pvs_norm_params& prm, float* d_out, float* d_inv_norm, bool raw = false);
+bool vlad_fused_eligible(const pvs_codebook* cb, const void* d_desc, int kind, int ld, const float* d_out);
+int launch_vlad_fused(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int ld, const int64_t* d_offsets,
+                      int64_t n_images, const pvs_norm_params& prm, float* d_out, int32_t* d_labels, float* d_inv_norm, bool raw = false);
 int launch_row_inv_norms(pvs_ctx* ctx, const float* d_x, int64_t rows, int64_t L, float* d_inv);
 int launch_cosine_f32(pvs_ctx* ctx, const float* A, int64_t M, const float* B, int64_t N, int64_t L,
                       const float* inva, const float* invb, float* out, int64_t ldo);
@@ -192,6 +200,7 @@ int launch_topk(pvs_ctx* ctx, const float* scores, int64_t nq, int64_t ncols, in
                 int64_t col_offset, int merge, int64_t* d_idx, float* d_val);
 int launch_topk_merge(pvs_ctx* ctx, const int64_t* idx_lists, const float* val_lists, int n_lists, int64_t nq,
                       int k, int64_t* d_idx, float* d_val);
+int launch_rank_f64(pvs_ctx* ctx, const double* scores, int64_t nq, int64_t ncols, int64_t ld, int k, int64_t* d_idx, double* d_val);
 int launch_pca(pvs_ctx* ctx, const pvs_pca* p, const void* d_desc, int kind, int64_t total, float* d_out);
 int launch_gmm_posterior(pvs_ctx* ctx, const pvs_gmm* g, const void* d_desc, int kind, int ld, int64_t total,
                          double* d_resp);

@@ -308,4 +308,85 @@ int launch_topk_merge(pvs_ctx* ctx, const int64_t* idx_lists, const float* val_l
   return launch_topk_impl(ctx, a);
 }
 
+// ------------------------------------------------------------------------------------------------- fp64 ranking
+// The reference ranks in float64 whenever an operand is float64 (Fisher encodings; pyvisim/_utils.py:312-330 returns the
+// dtype sklearn's cosine_similarity gives, eval.py then argsorts it).  Not a throughput path: one workgroup per query row,
+// the row's keys (order-preserving 64-bit image of the score, NaN last, -0 = +0) sorted in LDS by a bitonic network with the
+// index as tie break -- the same total order as the fp32 kernels: (score descending, index ascending).
+constexpr int R64_THREADS = 256;
+constexpr int R64_CHUNK = 8192;
+
+__device__ __forceinline__ uint64_t mono_f64(double f) {
+  if (f != f) return 1ull;
+  f += 0.0;
+  const uint64_t u = (uint64_t)__double_as_longlong(f);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double unmono_f64(uint64_t m) {
+  if (m == 1ull) return __longlong_as_double(0x7ff8000000000000ll);
+  return __longlong_as_double((long long)((m >> 63) ? (m & 0x7fffffffffffffffull) : ~m));
+}
+
+// sorts key[0..n2) / id[0..n2) (n2 a power of two) so that better entries come first
+__device__ __forceinline__ void bitonic_desc(uint64_t* key, uint32_t* id, int n2) {
+  for (int sz = 2; sz <= n2; sz <<= 1) {
+    for (int st = sz >> 1; st >= 1; st >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < (n2 >> 1); t += R64_THREADS) {
+        const int lo = ((t / st) * (st << 1)) + (t % st), hi = lo + st;
+        const bool desc = ((lo & sz) == 0);            // direction of this bitonic block
+        const uint64_t ka = key[lo], kb = key[hi];
+        const uint32_t ia = id[lo], ib = id[hi];
+        const bool a_first = ka > kb || (ka == kb && ia < ib);
+        if (a_first != desc) { key[lo] = kb; key[hi] = ka; id[lo] = ib; id[hi] = ia; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(R64_THREADS) void rank_f64_kernel(const double* __restrict__ scores, int64_t ncols, int64_t ld, int k,
+                                                               int64_t* __restrict__ oidx, double* __restrict__ oval) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* key = reinterpret_cast<uint64_t*>(smem);               // [R64_CHUNK]
+  uint32_t* id = reinterpret_cast<uint32_t*>(key + R64_CHUNK);     // [R64_CHUNK]
+  const int64_t q = blockIdx.x;
+  const double* row = scores + q * ld;
+  int have = 0;   // entries of the running list, kept sorted in key[0..have)
+  for (int64_t c0 = 0; c0 < ncols; c0 += R64_CHUNK - have) {
+    // the running list stays in front; the rest of the buffer takes the next columns
+    const int room = R64_CHUNK - have;
+    const int take = (int)((ncols - c0) < room ? (ncols - c0) : room);
+    int n2 = 1;
+    while (n2 < have + take) n2 <<= 1;
+    for (int t = threadIdx.x; t < n2 - have; t += R64_THREADS) {
+      const bool in = t < take;
+      key[have + t] = in ? mono_f64(row[c0 + t]) : 0ull;            // 0: below NaN's key, never selected before a real entry
+      id[have + t] = in ? (uint32_t)(c0 + t) : 0xffffffffu;
+    }
+    bitonic_desc(key, id, n2);
+    const int tot = have + take;
+    have = tot < k ? tot : k;
+    __syncthreads();
+  }
+  for (int t = threadIdx.x; t < k; t += R64_THREADS) {
+    const bool in = t < have;
+    oidx[q * k + t] = in ? (int64_t)id[t] : -1;
+    oval[q * k + t] = in ? unmono_f64(key[t]) : -INFINITY;
+  }
+}
+
+int launch_rank_f64(pvs_ctx* ctx, const double* scores, int64_t nq, int64_t ncols, int64_t ld, int k, int64_t* d_idx, double* d_val) {
+  if (nq <= 0 || k <= 0) return PVS_OK;
+  if (k > R64_CHUNK / 2 && ncols > R64_CHUNK)
+    PVS_FAIL(PVS_ERR_UNSUPPORTED, "float64 ranking deeper than %d over more than %d columns is not supported", R64_CHUNK / 2, R64_CHUNK);
+  if (ncols >= ((int64_t)1 << 32)) PVS_FAIL(PVS_ERR_UNSUPPORTED, "float64 ranking: too many columns");
+  const size_t lds = (size_t)R64_CHUNK * 12;
+  PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(rank_f64_kernel), lds));
+  ScopedTimer tm(ctx, T_TOPK);
+  hipLaunchKernelGGL(rank_f64_kernel, dim3((unsigned)nq), dim3(R64_THREADS), lds, ctx->stream, scores, ncols, ld, k, d_idx, d_val);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
 }  // namespace pvs

@@ -287,6 +287,18 @@ class Context:
                                          q.shape[1], int(k), ptr(idx), ptr(val)))
         return idx, val
 
+    def cosine_topk_f64(self, q, db, k: int):
+        """float64 scores and ranking (the reference's dtype whenever an operand is not float32, e.g. Fisher encodings)."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        db = np.ascontiguousarray(db, dtype=np.float64)
+        if q.shape[1] != db.shape[1]:
+            raise ValueError("query and database dimensions differ")
+        idx = np.empty((q.shape[0], k), dtype=np.int64)
+        val = np.empty((q.shape[0], k), dtype=np.float64)
+        check(_ffi.lib().pvs_cosine_topk_f64(self.handle, ptr(q), q.shape[0], ptr(db), db.shape[0], q.shape[1], int(k),
+                                             ptr(idx), ptr(val)))
+        return idx, val
+
     # ------------------------------------------------------------------ device-pointer forms
     # All pointer arguments are raw device addresses (int), e.g. torch.Tensor.data_ptr().
     def vlad_encode_dev(self, cb, d_desc, kind, d_offsets, n_images, total_desc, d_out, power=1.0, norm_order=2,

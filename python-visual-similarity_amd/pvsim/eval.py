@@ -41,9 +41,11 @@ def _rank(query_vecs: np.ndarray, all_vectors: np.ndarray, k: int | None, ctx=No
     if query_vecs.shape[-1] <= 1 or all_vectors.shape[-1] <= 1:
         raise ValueError(f"Cosine similarity requires at least 2 features. Got {query_vecs.shape[-1]} features "
                          f"for x and {all_vectors.shape[-1]} features for y.")
-    q32 = np.ascontiguousarray(query_vecs, dtype=np.float32)
-    d32 = np.ascontiguousarray(all_vectors, dtype=np.float32)
-    return ctx.cosine_topk(q32, d32, kk)
+    # the reference's dtype rule (pyvisim/_utils.py:312-330 -> sklearn): float32 scores iff BOTH operands are float32;
+    # anything else (Fisher encodings are float64) is scored and ranked in float64
+    if query_vecs.dtype == np.float32 and all_vectors.dtype == np.float32:
+        return ctx.cosine_topk(np.ascontiguousarray(query_vecs), np.ascontiguousarray(all_vectors), kk)
+    return ctx.cosine_topk_f64(query_vecs, all_vectors, kk)
 
 
 def retrieve_top_k_similar(uploaded_image: np.ndarray, dataset: dict[str, np.ndarray], encoder,

@@ -965,3 +965,106 @@ def test_u8_rootsift_short_sequence_equals_ieee(gpu_ctx):
     gpu_ctx.sync()
     want = orc.rootsift(raw)
     assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------- fused one-read encode (round 2)
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [DESC_F32, DESC_F32_ROOTSIFT, DESC_U8_ROOTSIFT])
+def test_fused_encode_equals_the_two_kernel_path(gpu_ctx, tables, kind):
+    """vlad_fused_kernel (every descriptor read once: prefilter scores, exact re-evaluation of near ties, residual sums in
+    descriptor order and normalisation in one persistent kernel) against assign + gather aggregate: labels, encodings and
+    1/||row|| bit for bit, on ragged images (empty, 1, 63, 64, 65, several stages, > 4096 rows) with rows the prefilter
+    cannot settle or cannot take (copies of centres, midpoints, zero rows, NaN / inf, far out of the table's scale)."""
+    import torch
+    C = tables["centroids"]
+    rng = np.random.default_rng(77 + kind)
+    counts = [0, 1, 63, 64, 65, 130, 512, 700, 0, 4100, 257, 31, 1411, 2, 199]
+    raws = [synth.sift_like(n, rng) for n in counts]
+    if kind == DESC_F32:
+        imgs = [synth.rootsift(r) if len(r) else np.zeros((0, 128), np.float32) for r in raws]
+        x = imgs[6]
+        x[5] = 0.0
+        x[6, 3] = np.nan
+        x[7, 9] = np.inf
+        x[8] = C[100]
+        x[9] = 0.5 * (C[3] + C[4])
+        x[10] *= 1e6
+        x[11] *= 1e-6
+        x[12] *= 1e30
+        x[13] = -x[13]
+        imgs[9][4000:4100] = 0.5 * (C[rng.integers(0, 256, 100)] + C[rng.integers(0, 256, 100)])   # near ties, last stage
+        dt = np.float32
+    elif kind == DESC_F32_ROOTSIFT:
+        imgs = [r.astype(np.float32) for r in raws]
+        imgs[6][5] = 0.0
+        dt = np.float32
+    else:
+        imgs = [r.astype(np.uint8) for r in raws]
+        imgs[6][5] = 0
+        dt = np.uint8
+    packed, off = pack_descriptors(imgs, 128, dt)
+    cb = gpu_ctx.codebook(C)
+    dev = torch.device("cuda", 0)
+    d_x = torch.from_numpy(packed).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    n, total = len(imgs), int(off[-1])
+    res = {}
+    for name, path in (("gather", _ffi.VLAD_PATH_GATHER), ("fused", _ffi.VLAD_PATH_FUSED)):
+        out = torch.full((n, 256 * 128), 7.0, dtype=torch.float32, device=dev)
+        lab = torch.full((total,), -5, dtype=torch.int32, device=dev)
+        inv = torch.full((n,), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        with gpu_ctx.option(_ffi.OPT_VLAD_PATH, path):
+            gpu_ctx.vlad_encode_dev(cb, d_x.data_ptr(), kind, d_off.data_ptr(), n, total, out.data_ptr(), d_labels=lab.data_ptr(),
+                                    d_inv_norm=inv.data_ptr())
+            gpu_ctx.sync()
+        res[name] = (out.cpu().numpy(), lab.cpu().numpy(), inv.cpu().numpy())
+    (o1, l1, i1), (o2, l2, i2) = res["gather"], res["fused"]
+    assert np.array_equal(l1, l2), np.argwhere(l1 != l2)[:10]
+    assert np.array_equal(o1.view(np.uint32), o2.view(np.uint32)), np.argwhere(o1.view(np.uint32) != o2.view(np.uint32))[:10]
+    assert np.array_equal(i1.view(np.uint32), i2.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("power,order,eps", [(0.5, 2, 1e-9), (1.0, 1, 1e-9), (0.3, np.inf, 1e-6), (1.0, 3.0, 0.0)])
+def test_fused_encode_normalisation_variants(gpu_ctx, tables, power, order, eps):
+    """The fused kernel's K3 epilogue in every normalisation mode, bit for bit against the gather kernel's epilogue."""
+    rng = np.random.default_rng(5)
+    imgs = [synth.rootsift(synth.sift_like(n, rng)) for n in (40, 300, 1, 129)]
+    packed, off = pack_descriptors(imgs, 128, np.float32)
+    cb = gpu_ctx.codebook(tables["centroids"])
+    with gpu_ctx.option(_ffi.OPT_VLAD_PATH, _ffi.VLAD_PATH_GATHER):
+        a = gpu_ctx.vlad_encode(cb, packed, off, DESC_F32, power, order, eps)
+    with gpu_ctx.option(_ffi.OPT_VLAD_PATH, _ffi.VLAD_PATH_FUSED):
+        b = gpu_ctx.vlad_encode(cb, packed, off, DESC_F32, power, order, eps)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_fused_encode_labels_equal_the_exact_kernel_on_many_rows(gpu_ctx, tables):
+    """2 M RootSIFT-like rows plus 2e5 engineered near ties: the fused kernel's labels against the exact f32 MFMA kernel's
+    (PVS_OPT_ASSIGN_PREFILTER = 0)."""
+    import torch
+    C = tables["centroids"]
+    rng = np.random.default_rng(2024)
+    dev = torch.device("cuda", 0)
+    x = synth.rootsift(synth.sift_like(2_000_000, rng))
+    a_, b_ = rng.integers(0, 256, 200_000), rng.integers(0, 256, 200_000)
+    t = rng.uniform(0.4999, 0.5001, size=(200_000, 1)).astype(np.float32)
+    ties = (t * C[a_] + (1 - t) * C[b_]).astype(np.float32)
+    x = np.concatenate([x, ties])
+    n_img = 1100
+    off = np.linspace(0, len(x), n_img + 1).astype(np.int64)
+    cb = gpu_ctx.codebook(C)
+    d_x = torch.from_numpy(x).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    out = torch.empty((n_img, 256 * 128), dtype=torch.float32, device=dev)
+    labs = []
+    for pre in (0, 1):
+        lab = torch.full((len(x),), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        with gpu_ctx.option(_ffi.OPT_ASSIGN_PREFILTER, pre):
+            gpu_ctx.vlad_encode_dev(cb, d_x.data_ptr(), DESC_F32, d_off.data_ptr(), n_img, len(x), out.data_ptr(), d_labels=lab.data_ptr())
+            gpu_ctx.sync()
+        labs.append(lab.cpu().numpy())
+    assert np.array_equal(labs[0], labs[1]), (np.argwhere(labs[0] != labs[1])[:10], int((labs[0] != labs[1]).sum()))
