@@ -87,8 +87,40 @@ PVS_EXPORT int pvs_device_count(int* count) {
   return PVS_OK;
 }
 
+// Paths of the HIP runtime images mapped into this process (Linux: /proc/self/maps).  Two of them -- e.g. the system runtime
+// this library was linked against plus the copy a PyTorch wheel bundles -- each open the device on their own and the second
+// one finds no GPU; device pointers and streams cannot cross between them either.
+static int count_hip_runtimes(char* first, size_t flen, char* second, size_t slen) {
+  FILE* f = fopen("/proc/self/maps", "r");
+  if (!f) return 0;
+  char line[4096];
+  int n = 0;
+  first[0] = second[0] = 0;
+  while (fgets(line, sizeof(line), f)) {
+    char* p = strchr(line, '/');
+    if (!p) continue;
+    char* nl = strchr(p, '\n');
+    if (nl) *nl = 0;
+    const char* base = strrchr(p, '/');
+    if (!base || !strstr(base, "libamdhip64")) continue;
+    if (n >= 1 && strcmp(first, p) == 0) continue;
+    if (n >= 2 && strcmp(second, p) == 0) continue;
+    if (n == 0) snprintf(first, flen, "%s", p);
+    else if (n == 1) snprintf(second, slen, "%s", p);
+    ++n;
+  }
+  fclose(f);
+  return n;
+}
+
 PVS_EXPORT int pvs_init(int device_id, void* stream, pvs_ctx** out) {
   PVS_NEED(out, "out");
+  {
+    char a[512], b[512];
+    if (count_hip_runtimes(a, sizeof(a), b, sizeof(b)) > 1)
+      PVS_FAIL(PVS_ERR_NO_DEVICE, "two HIP runtimes are mapped in this process (%s and %s): load libpvsim_hip.so after the runtime the "
+               "rest of the process uses (the pvsim Python package does this by itself)", a, b);
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     PVS_FAIL(PVS_ERR_NO_DEVICE, "no HIP device visible: this engine has no CPU fallback");

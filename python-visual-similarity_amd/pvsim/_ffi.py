@@ -93,6 +93,43 @@ _lib = None
 _lock = threading.Lock()
 
 
+def mapped_hip_runtimes() -> list[str]:
+    """Paths of the HIP runtime images (libamdhip64) mapped into this process."""
+    found = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1] if "/" in line else ""
+                if "libamdhip64" in os.path.basename(path) and path not in found:
+                    found.append(path)
+    except OSError:
+        pass
+    return found
+
+
+def _one_hip_runtime() -> None:
+    """One HIP runtime per process, whatever the import order.
+
+    libpvsim_hip.so needs `libamdhip64.so.7`.  A PyTorch-ROCm wheel ships its own copy under torch/lib with that same
+    SONAME, and two runtimes in one process each open the device on their own (the second one then sees no GPU).  The
+    dynamic linker binds a DT_NEEDED entry to an already mapped object of that SONAME, so all that is needed is that the
+    FIRST runtime mapped is the one everybody else will ask for: if none is mapped yet and torch is installed, map
+    torch's copy now (a later `import torch` finds the same file); without torch the system runtime under /opt/rocm is
+    used.  pvs_init refuses to run when it finds two runtimes mapped."""
+    if mapped_hip_runtimes():
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for loc in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
+        cand = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return
+
+
 def lib():
     """The loaded shared library (loads on first use; raises ImportError if it is not built)."""
     global _lib
@@ -104,6 +141,7 @@ def lib():
                         f"{LIB_PATH} not found: build the HIP library first "
                         "(python -c 'import __graft_entry__ as g; g.build()' or make -C python-visual-similarity_amd/csrc). "
                         "pvsim has no CPU fallback.")
+                _one_hip_runtime()
                 l = C.CDLL(LIB_PATH)
                 for name, args in SIGNATURES.items():
                     fn = getattr(l, name)          # AttributeError here = header / library mismatch

@@ -114,15 +114,6 @@ class Context:
 
     def __init__(self, device: int = 0, stream: int | None = None):
         self.handle = None
-        # If torch is already loaded, let it open the GPU first: on some hosts a process whose HIP runtime was opened here
-        # before torch's own initialisation leaves torch without a device ("No HIP GPUs are available").
-        _t = sys.modules.get("torch")
-        if _t is not None:
-            try:
-                if _t.cuda.is_available():
-                    _t.cuda.init()
-            except Exception:
-                pass
         h = C.c_void_p()
         check(_ffi.lib().pvs_init(int(device), C.c_void_p(stream), C.byref(h)))
         self.handle = h

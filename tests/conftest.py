@@ -10,6 +10,8 @@ for p in (REPO, os.path.join(REPO, "python-visual-similarity_amd"), os.path.join
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
+if GOLDEN not in sys.path:
+    sys.path.insert(0, GOLDEN)        # config3_inputs.py: seeded inputs shared with the fixture generator
 
 
 def pytest_configure(config):
@@ -30,12 +32,6 @@ def gpu_ctx():
     """One engine context on cuda:0 for the whole GPU session (fails loudly if the HIP
     library is missing or no device is present -- there is no CPU fallback)."""
     import pvsim
-    try:    # torch first: on the test boxes a process whose HIP runtime was opened by the engine before torch's own
-        import torch    # initialisation leaves torch without a GPU ("No HIP GPUs are available"); the other order works
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except ImportError:
-        pass
     ctx = pvsim.Context(0)
     yield ctx
     ctx.close()

@@ -3,7 +3,12 @@
 
 Run in the build container only (it needs /root/reference, which never travels):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py            # (re)write the fixtures
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --check    # run the reference again, assert bit-equality
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --refit    # fit new tables (changes every fixture)
+
+The codebook / GMM / PCA tables are read from the committed tables_k256_d128.npz when it exists (KMeans' OpenMP chunk sums
+make a re-fit differ in the last bits from run to run), so a fresh run reproduces the committed files bit for bit.
 
 What it does
   * imports pyvisim's own VLADEncoder / FisherVectorEncoder / Pipeline / cosine_similarity / eval
@@ -112,7 +117,44 @@ def _import_reference():
     return VLADEncoder, FisherVectorEncoder, Pipeline, Lambda, cosine_similarity, ref_eval
 
 
+def _kmeans_with_centres(C, seed=0):
+    """A fitted KMeans whose centres are exactly C (one-iteration fit, then overwrite)."""
+    from sklearn.cluster import KMeans
+    C = np.ascontiguousarray(C, dtype=np.float32)
+    km = KMeans(n_clusters=C.shape[0], init=C, n_init=1, max_iter=1, random_state=seed).fit(C)
+    km.cluster_centers_ = C.copy()
+    return km
+
+
+def _gmm_with_tables(w, mu, cov):
+    from sklearn.mixture import GaussianMixture
+    g = GaussianMixture(n_components=len(w), covariance_type="diag")
+    g.weights_, g.means_, g.covariances_ = np.asarray(w, np.float64), np.asarray(mu, np.float64), np.asarray(cov, np.float64)
+    g.precisions_cholesky_ = 1.0 / np.sqrt(g.covariances_)       # sklearn _compute_precision_cholesky, 'diag'
+    g.precisions_ = g.precisions_cholesky_ ** 2
+    g.converged_, g.n_iter_, g.lower_bound_ = True, 1, 0.0
+    g.n_features_in_ = g.means_.shape[1]
+    return g
+
+
+def _pca_with_tables(components, mean):
+    from sklearn.decomposition import PCA
+    p = PCA(n_components=components.shape[0])
+    # a fitted PCA keeps components_ as the transposed (Fortran-ordered) eigenvector block; the GEMM of transform() takes a
+    # different BLAS path for a C-ordered copy, so the layout is part of reproducing the fitted object bit for bit
+    p.components_, p.mean_ = np.asfortranarray(components), np.asarray(mean)
+    p.n_components_, p.n_features_in_, p.whiten = components.shape[0], components.shape[1], False
+    p.explained_variance_ = np.ones(components.shape[0], components.dtype)
+    return p
+
+
+sys.path.insert(0, HERE)
+from config3_inputs import config3_inputs  # noqa: E402  (shared with the tests)
+
+
 def main() -> None:
+    check = "--check" in sys.argv
+    refit = "--refit" in sys.argv
     from sklearn.cluster import KMeans
     from sklearn.decomposition import PCA
     from sklearn.mixture import GaussianMixture
@@ -123,29 +165,63 @@ def main() -> None:
     warnings.simplefilter("ignore")
     out = {}
 
+    bad = []
+
     def save(name, **arrays):
         path = os.path.join(HERE, name + ".npz")
-        np.savez_compressed(path, **arrays)
         out[name] = {k: [list(np.shape(v)), str(np.asarray(v).dtype)] for k, v in arrays.items()}
+        if not os.path.exists(path):
+            if check:
+                bad.append(f"{name}.npz (missing)")
+                return
+        else:
+            old = np.load(path, allow_pickle=False)
+            n_bad = len(bad)
+            for k, v in arrays.items():
+                v = np.asarray(v)
+                same = k in old.files and old[k].shape == v.shape and old[k].dtype == v.dtype and \
+                    np.ascontiguousarray(old[k]).tobytes() == np.ascontiguousarray(v).tobytes()
+                if not same:
+                    bad.append(f"{name}.npz:{k}")
+            same_file = len(bad) == n_bad and sorted(old.files) == sorted(arrays)
+            if check:
+                print(f"  checked {name}.npz: {'ok' if same_file else 'DIFFERS'}")
+                return
+            del bad[n_bad:]
+            if same_file:
+                print(f"  {name}.npz unchanged")       # not rewritten: a zip archive carries time stamps
+                return
+        np.savez_compressed(path, **arrays)
         print(f"  wrote {name}.npz  ({os.path.getsize(path)/1e6:.2f} MB)")
 
     proto = synth.sift_prototypes()
     rootsift_x = Lambda(synth.rootsift, 128)
 
     # ---------------------------------------------------------------- tables (fit here, seeded)
-    rng = np.random.default_rng(20240)
-    train = synth.rootsift(synth.sift_like(60000, rng, proto))
-    km = KMeans(n_clusters=256, n_init=1, max_iter=25, random_state=0).fit(train)
-    C = np.ascontiguousarray(km.cluster_centers_, dtype=np.float32)
-    km.cluster_centers_ = C.copy()
-    gmm = GaussianMixture(n_components=256, covariance_type="diag", max_iter=15, random_state=0,
-                          init_params="kmeans").fit(train[:40000].astype(np.float64))
-    pca = PCA(n_components=64, random_state=0).fit(train[:20000])
-    trainp = pca.transform(train[:40000])
-    km_p = KMeans(n_clusters=256, n_init=1, max_iter=15, random_state=1).fit(trainp)
-    km_p.cluster_centers_ = np.ascontiguousarray(km_p.cluster_centers_, dtype=np.float32)
-    gmm_p = GaussianMixture(n_components=64, covariance_type="diag", max_iter=10,
-                            random_state=1).fit(trainp.astype(np.float64))
+    tab_path = os.path.join(HERE, "tables_k256_d128.npz")
+    if os.path.exists(tab_path) and not refit:
+        T = np.load(tab_path, allow_pickle=False)
+        C = np.ascontiguousarray(T["centroids"], dtype=np.float32)
+        km = _kmeans_with_centres(C)
+        gmm = _gmm_with_tables(T["gmm_weights"], T["gmm_means"], T["gmm_covariances"])
+        pca = _pca_with_tables(T["pca_components"], T["pca_mean"])
+        km_p = _kmeans_with_centres(T["centroids_pca64"], 1)
+        gmm_p = _gmm_with_tables(T["gmmp_weights"], T["gmmp_means"], T["gmmp_covariances"])
+        print("  tables: loaded from the committed tables_k256_d128.npz")
+    else:
+        rng = np.random.default_rng(20240)
+        train = synth.rootsift(synth.sift_like(60000, rng, proto))
+        km = KMeans(n_clusters=256, n_init=1, max_iter=25, random_state=0).fit(train)
+        C = np.ascontiguousarray(km.cluster_centers_, dtype=np.float32)
+        km.cluster_centers_ = C.copy()
+        gmm = GaussianMixture(n_components=256, covariance_type="diag", max_iter=15, random_state=0,
+                              init_params="kmeans").fit(train[:40000].astype(np.float64))
+        pca = PCA(n_components=64, random_state=0).fit(train[:20000])
+        trainp = pca.transform(train[:40000])
+        km_p = KMeans(n_clusters=256, n_init=1, max_iter=15, random_state=1).fit(trainp)
+        km_p.cluster_centers_ = np.ascontiguousarray(km_p.cluster_centers_, dtype=np.float32)
+        gmm_p = GaussianMixture(n_components=64, covariance_type="diag", max_iter=10,
+                                random_state=1).fit(trainp.astype(np.float64))
     save("tables_k256_d128",
          centroids=C,
          gmm_weights=gmm.weights_, gmm_means=gmm.means_, gmm_covariances=gmm.covariances_,
@@ -175,12 +251,19 @@ def main() -> None:
     rng = np.random.default_rng(5)
     Ks, Ds = 16, 8
     small_train = rng.random((4000, Ds)).astype(np.float32)
-    km_s = KMeans(n_clusters=Ks, n_init=1, max_iter=10, random_state=2).fit(small_train)
-    Cs = np.ascontiguousarray(km_s.cluster_centers_, dtype=np.float32)
-    Cs[5] = Cs[3]           # duplicated centroid -> exact tie, first index must win (G6)
-    km_s.cluster_centers_ = Cs.copy()
-    gmm_s = GaussianMixture(n_components=Ks, covariance_type="diag", max_iter=10,
-                            random_state=2).fit(small_train.astype(np.float64))
+    small_path = os.path.join(HERE, "small_k16_d8.npz")
+    if os.path.exists(small_path) and not refit:
+        S_ = np.load(small_path, allow_pickle=False)
+        Cs = np.ascontiguousarray(S_["centroids"], dtype=np.float32)
+        km_s = _kmeans_with_centres(Cs, 2)
+        gmm_s = _gmm_with_tables(S_["gmm_weights"], S_["gmm_means"], S_["gmm_covariances"])
+    else:
+        km_s = KMeans(n_clusters=Ks, n_init=1, max_iter=10, random_state=2).fit(small_train)
+        Cs = np.ascontiguousarray(km_s.cluster_centers_, dtype=np.float32)
+        Cs[5] = Cs[3]           # duplicated centroid -> exact tie, first index must win (G6)
+        km_s.cluster_centers_ = Cs.copy()
+        gmm_s = GaussianMixture(n_components=Ks, covariance_type="diag", max_iter=10,
+                                random_state=2).fit(small_train.astype(np.float64))
     ident = Lambda(lambda im: im.astype(np.float32) / np.float32(16.0), Ds)
     small_raw = [rng.integers(0, 17, size=(n, Ds)).astype(np.float32) for n in (1, 3, 40, 40, 333)]
     small_raw[3] = small_raw[2].copy()  # duplicate image -> tied similarity rows
@@ -285,6 +368,43 @@ def main() -> None:
          sims=sims, full_argsort=np.argsort(-sims, axis=1).astype(np.int64),
          **{k: np.float64(v) for k, v in res.items()})
 
+    # ---------------------------------------------------------------- eval.* with a FisherVectorEncoder: float64 scores, float64 ranking
+    fdb = fenc.encode(db_raw)
+    assert fdb.dtype == np.float64
+    f_map = dict(zip(paths, fdb))
+    f_top = [ref_eval.retrieve_top_k_similar([q], f_map, fenc, k=7) for q in q_raw]
+    f_res = {
+        "acc_k1": ref_eval.top_k_accuracy(wrapped, list(q_lab), f_map, path_labels, fenc, 1),
+        "acc_k5": ref_eval.top_k_accuracy(wrapped, list(q_lab), f_map, path_labels, fenc, 5),
+        "map_all": ref_eval.top_k_map(wrapped, list(q_lab), f_map, path_labels, fenc, None),
+        "map_k5": ref_eval.top_k_map(wrapped, list(q_lab), f_map, path_labels, fenc, 5),
+    }
+    f_sims = ref_cos(fenc.encode(q_raw), fdb)
+    assert f_sims.dtype == np.float64 and all(isinstance(sc, np.float64) for _, sc in f_top[0])
+    save("eval_fisher_db64",
+         top7_index=np.asarray([[paths.index(p) for p, _ in t] for t in f_top], np.int64),
+         top7_score=np.asarray([[sc for _, sc in t] for t in f_top], np.float64),
+         sims=f_sims, full_argsort=np.argsort(-f_sims, axis=1).astype(np.int64),
+         **{k: np.float64(v) for k, v in f_res.items()})
+
+    # ---------------------------------------------------------------- BASELINE configs[2] shape: Fisher D = 512, K = 256, n = 196
+    # inputs and tables are regenerated from the seed wherever they are needed (config3_inputs); the fixture keeps the
+    # reference's outputs only: image 0 whole, every 32nd element of all 12 images, and the row norms
+    w3, mu3, cov3, imgs3 = config3_inputs(12)
+    store3 = {i: d for i, d in enumerate(imgs3)}
+    x3 = Lambda(lambda im: store3[int(im[0, 0])], 512)
+    F3 = FisherVectorEncoder(feature_extractor=x3, gmm_model=_gmm_with_tables(w3, mu3, cov3)).encode(
+        [np.array([[i]], dtype=np.int64) for i in range(12)])
+    assert F3.shape == (12, 256 + 2 * 256 * 512) and F3.dtype == np.float64
+    save("fisher_k256_d512", image0=F3[0], every32=np.ascontiguousarray(F3[:, ::32]), cos_self=ref_cos(F3, F3),
+         desc_checksum=np.float64(sum(float(d.astype(np.float64).sum()) for d in imgs3)))
+
+    if check:
+        if bad:
+            print("DIFFERENT from the committed fixtures:", *bad, sep="\n  ")
+            sys.exit(1)
+        print("all fixtures reproduced bit for bit")
+        return
     meta = {"numpy": np.__version__, "scikit-learn": sklearn.__version__, "scipy": scipy.__version__,
             "joblib": joblib.__version__, "python": sys.version.split()[0],
             "reference": "MechaCritter/Python-Visual-Similarity pyvisim 0.1.3 (/root/reference)",

@@ -242,3 +242,41 @@ def test_learn_restatement_matches_the_reference_fits():
     assert n_iter == int(g["g_n_iter"]) and conv == bool(g["g_converged"])
     for a, b in ((w, "g_weights"), (mu, "g_means"), (cov, "g_cov")):
         np.testing.assert_allclose(a, g[b], rtol=1e-10, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------------- round 2 fixtures
+def _config3():
+    from config3_inputs import config3_inputs
+    return config3_inputs(12)
+
+
+def test_oracle_fisher_at_the_config3_shape():
+    """BASELINE configs[2]: Fisher, D = 512, K = 256, n = 196 -- the NumPy restatement against the reference's own output
+    (image 0 whole, every 32nd element of 12 images, the 12 x 12 float64 cosine matrix)."""
+    g = load_golden("fisher_k256_d512")
+    w, mu, cov, imgs = _config3()
+    assert abs(sum(float(d.astype(np.float64).sum()) for d in imgs) - float(g["desc_checksum"])) < 1e-6   # same seeded inputs
+    f = orc.fisher_encode(imgs, w, mu, cov)
+    assert f.dtype == np.float64 and f.shape == (12, 256 + 2 * 256 * 512)
+    np.testing.assert_allclose(f[0], g["image0"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(f[:, ::32], g["every32"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(orc.cosine_similarity(f, f), g["cos_self"], rtol=0, atol=1e-12)
+
+
+def test_oracle_eval_with_fisher_vectors_ranks_in_float64(tables):
+    g, e = load_golden("eval_fisher_db64"), load_golden("eval_db64")
+    db = [orc.rootsift(r.astype(np.float32)) for r in orc.split_ragged(e["db_raw_u8"], e["db_offsets"])]
+    qs = [orc.rootsift(r.astype(np.float32)) for r in orc.split_ragged(e["q_raw_u8"], e["q_offsets"])]
+    fdb = orc.fisher_encode(db, tables["gmm_weights"], tables["gmm_means"], tables["gmm_covariances"])
+    fq = orc.fisher_encode(qs, tables["gmm_weights"], tables["gmm_means"], tables["gmm_covariances"])
+    sims = orc.cosine_similarity(fq, fdb)
+    assert sims.dtype == np.float64
+    np.testing.assert_allclose(sims, g["sims"], rtol=0, atol=1e-12)
+    idx, val = orc.topk(sims, 7)
+    assert np.array_equal(idx, g["top7_index"])
+    np.testing.assert_allclose(val, g["top7_score"], rtol=0, atol=1e-12)
+    assert np.array_equal(orc.argsort_desc(sims), g["full_argsort"])
+    assert orc.top_k_accuracy(fq, e["q_labels"], fdb, e["db_labels"], 1) == float(g["acc_k1"])
+    assert orc.top_k_accuracy(fq, e["q_labels"], fdb, e["db_labels"], 5) == float(g["acc_k5"])
+    assert abs(orc.top_k_map(fq, e["q_labels"], fdb, e["db_labels"], None) - float(g["map_all"])) < 1e-12
+    assert abs(orc.top_k_map(fq, e["q_labels"], fdb, e["db_labels"], 5) - float(g["map_k5"])) < 1e-12
