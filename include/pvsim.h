@@ -53,8 +53,8 @@ typedef enum {
  * tests and benchmarks can pin one of several implementations that must agree bit for bit. */
 typedef enum {
   PVS_OPT_ASSIGN_PREFILTER = 0, /* 1 (default): fp16 MFMA prefilter + exact pass on near ties; 0: exact f32 MFMA kernel only      */
-  PVS_OPT_VLAD_PATH = 1,        /* 0 (default): fused one-read encode when the shape qualifies, else 1; 1: assign + gather         */
-                                /* aggregate (two reads); 2: assign + streaming aggregate; 3: fused, error if the shape does not qualify */
+  PVS_OPT_VLAD_PATH = 1,        /* 0 (default) and 1: assign + gather aggregate (two reads of the descriptors); 2: assign +        */
+                                /* streaming aggregate; 3: fused one-read kernel (D = 128, 128 < K <= 256; error otherwise)        */
   PVS_OPT_TOPK_SELECT_ONLY = 2, /* 0 (default): k <= 16 takes the k-rounds kernel; 1: always the radix-select kernel               */
   PVS_OPT_COUNT_ = 3
 } pvs_option;
@@ -63,6 +63,7 @@ typedef struct pvs_ctx pvs_ctx;
 typedef struct pvs_codebook pvs_codebook; /* KMeans.cluster_centers_ (K,D) f32 + ||c||^2                */
 typedef struct pvs_gmm pvs_gmm;           /* GaussianMixture weights_/means_/covariances_ ('diag')     */
 typedef struct pvs_pca pvs_pca;           /* PCA components_ (C,Din) + mean_                            */
+typedef struct pvs_comm pvs_comm;         /* one rank of the multi-GPU exchange (RCCL communicator bound to a context)  */
 
 /* Normalisation knobs shared by both encoders -- the constructor kwargs of
  * VLADEncoder (pyvisim/encoders/vlad.py:42-53) and FisherVectorEncoder (fisher_vector.py:41-51). */
@@ -92,6 +93,12 @@ int pvs_free(pvs_ctx* ctx, void* dptr);
 int pvs_memcpy_h2d(pvs_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int pvs_memcpy_d2h(pvs_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int pvs_memset(pvs_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* 4- or 8-byte pattern fill of device memory on the context's stream (list buffers: -1 indices, -inf scores). */
+int pvs_fill_dev(pvs_ctx* ctx, void* dst_dev, int64_t n_elems, int elem_bytes, uint64_t pattern);
+/* Stream ordering between two contexts of one process (e.g. compute and exchange): work queued on `waiter` after this
+ * call starts only when everything queued on `signal` before this call has finished.  No host synchronisation. */
+int pvs_stream_wait(pvs_ctx* waiter, pvs_ctx* signal);
 
 /* ---------------------------------------------------------------- tables (host pointers in) */
 /* replaces reading KMeans.cluster_centers_ per image (vlad.py:96) */
@@ -196,6 +203,28 @@ int pvs_cosine_topk_filtered_dev(pvs_ctx* ctx, const float* d_Q, int64_t nq, con
 int pvs_topk_merge_dev(pvs_ctx* ctx, const int64_t* d_idx_lists, const float* d_val_lists, int n_lists,
                        int64_t nq, int k, int64_t* d_idx, float* d_val);
 
+/* ---------------------------------------------------------------- multi-GPU exchange (one process per GPU, RCCL over xGMI)
+ * The path shards by image (images are independent: pyvisim/encoders/vlad.py:87-113; global index = block offset + local
+ * index, the insertion order of pyvisim/eval.py:28); the pairwise step needs ONE exchange of the encoding blocks, plus one
+ * all-to-all of k-candidate lists in the symmetric block-pair scheme (pvsim/distributed.py).  librccl is resolved at
+ * pvs_comm_init (an image already mapped in the process is preferred); collectives are enqueued on the context's stream.
+ * Bootstrap: rank 0 calls pvs_comm_unique_id and hands the 128 bytes to the other ranks by any host channel. */
+#define PVS_UNIQUE_ID_BYTES 128
+int pvs_comm_unique_id(void* out_id /*[128]*/);
+int pvs_comm_init(pvs_ctx* ctx, int nranks, int rank, const void* unique_id /*[128]*/, pvs_comm** out);
+int pvs_comm_destroy(pvs_comm* comm);
+const char* pvs_comm_library(void);   /* which librccl image was bound ("" before the first pvs_comm_init) */
+/* recv[r * bytes_per_rank ...] = rank r's send block, for every r */
+int pvs_allgather_dev(pvs_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* recv[p * bytes_per_rank ...] = the block rank p addressed to this rank (its send[this rank]) */
+int pvs_alltoall_dev(pvs_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* batched point-to-point: op i sends send_bytes[i] bytes to and receives recv_bytes[i] bytes from peers[i] (either may be 0) */
+int pvs_sendrecv_dev(pvs_comm* comm, int n_ops, const int* peers, const void* const* d_send, const size_t* send_bytes,
+                     void* const* d_recv, const size_t* recv_bytes);
+/* element-wise maximum over the ranks of up to 64 host doubles (timing: slowest rank); synchronises the stream */
+int pvs_allreduce_max_f64(pvs_comm* comm, double* h_inout, int count);
+int pvs_comm_barrier(pvs_comm* comm);
+
 /* ---------------------------------------------------------------- vocabulary training
  * Replaces the sklearn fits inside ImageEncoderBase.learn (pyvisim/encoders/_base_encoder.py:311-342: PCA.fit ->
  * KMeans.fit for VLAD / GaussianMixture(covariance_type="diag").fit for Fisher).  Each entry is ONE pass over the
@@ -238,6 +267,12 @@ int pvs_min_update_dev(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t
 int pvs_timers_enable(pvs_ctx* ctx, int on);
 int pvs_timers_reset(pvs_ctx* ctx);
 int pvs_timers_read(pvs_ctx* ctx, int which, double* total_ms, int64_t* launches);
+
+/* Diagnostic build of the fused VLAD encode (in-kernel cycle stamps of one wave per workgroup; the product kernel carries
+ * none).  enable != 0: following fused launches run the stamped kernel and add into 16 counters; out16 (optional) receives and
+ * resets them: [0..6] shader cycles in P0 / A / reduce / exact re-evaluation / K2 / epilogue / image switch summed over the
+ * workgroups, [8] stages, [9] stages with a re-evaluation, [10] re-evaluation entries, [11] rows the margin did not settle. */
+int pvs_fused_profile(pvs_ctx* ctx, int enable, int64_t* out16);
 
 #ifdef __cplusplus
 }

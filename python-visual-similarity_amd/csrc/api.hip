@@ -154,6 +154,7 @@ PVS_EXPORT int pvs_destroy(pvs_ctx* ctx) {
   for (auto& p : ctx->gemm_plan)
     if (p.d_tiles) hipFree(p.d_tiles);
   if (ctx->d_queue) hipFree(ctx->d_queue);
+  if (ctx->d_fused_stamps) hipFree(ctx->d_fused_stamps);
   if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return PVS_OK;
@@ -222,6 +223,42 @@ PVS_EXPORT int pvs_memcpy_d2h(pvs_ctx* ctx, void* dst, const void* src, size_t b
 PVS_EXPORT int pvs_memset(pvs_ctx* ctx, void* dst, int value, size_t bytes) {
   PVS_NEED(ctx, "ctx");
   PVS_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+  return PVS_OK;
+}
+
+namespace pvs {
+__global__ void fill32_kernel(uint32_t* p, int64_t n, uint32_t v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void fill64_kernel(uint64_t* p, int64_t n, uint64_t v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+}  // namespace pvs
+
+PVS_EXPORT int pvs_fill_dev(pvs_ctx* ctx, void* dst, int64_t n, int elem_bytes, uint64_t pattern) {
+  PVS_NEED(ctx, "ctx");
+  if (n <= 0) return PVS_OK;
+  PVS_NEED(dst, "dst");
+  if (elem_bytes != 4 && elem_bytes != 8) PVS_FAIL(PVS_ERR_INVALID, "fill: 4- or 8-byte elements");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->num_cu * 8);
+  if (elem_bytes == 4) hipLaunchKernelGGL(fill32_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<uint32_t*>(dst), n, (uint32_t)pattern);
+  else hipLaunchKernelGGL(fill64_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<uint64_t*>(dst), n, pattern);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+PVS_EXPORT int pvs_stream_wait(pvs_ctx* waiter, pvs_ctx* signal) {
+  PVS_NEED(waiter, "waiter");
+  PVS_NEED(signal, "signal");
+  if (waiter->device != signal->device) PVS_FAIL(PVS_ERR_INVALID, "pvs_stream_wait: contexts on different devices");
+  if (waiter->stream == signal->stream) return PVS_OK;
+  PVS_HIP(hipSetDevice(waiter->device));
+  hipEvent_t ev;
+  PVS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  PVS_HIP(hipEventRecord(ev, signal->stream));
+  PVS_HIP(hipStreamWaitEvent(waiter->stream, ev, 0));
+  PVS_HIP(hipEventDestroy(ev));     // released by the runtime once the recorded work has completed
   return PVS_OK;
 }
 
@@ -494,13 +531,14 @@ PVS_EXPORT int pvs_vlad_encode_dev(pvs_ctx* ctx, const pvs_codebook* cb, const p
   int kind = desc_kind, ld = 0;
   const void* x = d_desc;
   PVS_TRY(project_if_needed(ctx, pca, cb->D, x, kind, total_desc, ld));
-  // one pass over the descriptors when the table shape qualifies (vlad_fused.hip); PVS_OPT_VLAD_PATH pins a path
+  // PVS_OPT_VLAD_PATH = 3: the one-read fused kernel (vlad_fused.hip).  It is bit-identical to the two-kernel path and moves
+  // half the bytes, but its phases are latency-bound today, so the default stays assign + aggregate.
   const int path = ctx->opt[PVS_OPT_VLAD_PATH];
-  const bool fused_ok = ctx->opt[PVS_OPT_ASSIGN_PREFILTER] != 0 && vlad_fused_eligible(cb, x, kind, ld, d_out);
-  if (path == 3 && !fused_ok)
-    PVS_FAIL(PVS_ERR_UNSUPPORTED, "fused VLAD encode needs D = 128, 128 < K <= 256, aligned rows and the fp16 prefilter tables");
-  if ((path == 0 || path == 3) && fused_ok)
+  if (path == 3) {
+    if (!(ctx->opt[PVS_OPT_ASSIGN_PREFILTER] != 0 && vlad_fused_eligible(cb, x, kind, ld, d_out)))
+      PVS_FAIL(PVS_ERR_UNSUPPORTED, "fused VLAD encode needs D = 128, 128 < K <= 256, aligned rows and the fp16 prefilter tables");
     return launch_vlad_fused(ctx, cb, x, kind, ld, d_offsets, n_images, *prm, d_out, d_labels, d_inv_norm);
+  }
   int32_t* labels = d_labels;
   if (!labels)
     PVS_TRY(ws_reserve(ctx, 1, (size_t)std::max<int64_t>(total_desc, 1) * sizeof(int32_t),
@@ -1051,6 +1089,25 @@ PVS_EXPORT int pvs_min_update_dev(pvs_ctx* ctx, float* d_mind, const float* d_di
   PVS_TRY(ws_reserve(ctx, 2, nblk * sizeof(double), reinterpret_cast<void**>(&d_bs)));
   PVS_TRY(launch_min_update(ctx, d_mind, d_dist, total_desc, d_bs));
   return stats_to_host(ctx, d_bs, nblk, h_block_sums);
+}
+
+// ================================================================================ diagnostics
+PVS_EXPORT int pvs_fused_profile(pvs_ctx* ctx, int enable, int64_t* out16) {
+  PVS_NEED(ctx, "ctx");
+  PVS_HIP(hipSetDevice(ctx->device));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  if (out16) {
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    if (ctx->d_fused_stamps) PVS_HIP(hipMemcpy(out16, ctx->d_fused_stamps, 16 * 8, hipMemcpyDeviceToHost));
+  }
+  if (enable) {
+    if (!ctx->d_fused_stamps) PVS_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_fused_stamps), 16 * 8));
+    PVS_HIP(hipMemset(ctx->d_fused_stamps, 0, 16 * 8));
+  } else if (ctx->d_fused_stamps) {
+    PVS_HIP(hipFree(ctx->d_fused_stamps));
+    ctx->d_fused_stamps = nullptr;
+  }
+  return PVS_OK;
 }
 
 // ================================================================================ timers

@@ -76,6 +76,7 @@ struct pvs_ctx {
   // behaviour switches (pvs_set_option); defaults = the product path
   int opt[PVS_OPT_COUNT_] = {1, 0, 0};
   unsigned int* d_queue = nullptr;   // image queue head of the fused encode (persistent workgroups)
+  unsigned long long* d_fused_stamps = nullptr;   // non-null: fused launches run the stamped diagnostic kernel (pvs_fused_profile)
   // timers
   bool timers_on = false;
   std::vector<pvs::TimerRec> pending;

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(R64_THREADS) void rank_f64_kernel(const double* __r
   const int64_t q = blockIdx.x;
   const double* row = scores + q * ld;
   int have = 0;   // entries of the running list, kept sorted in key[0..have)
-  for (int64_t c0 = 0; c0 < ncols; c0 += R64_CHUNK - have) {
+  for (int64_t c0 = 0; c0 < ncols;) {
     // the running list stays in front; the rest of the buffer takes the next columns
     const int room = R64_CHUNK - have;
     const int take = (int)((ncols - c0) < room ? (ncols - c0) : room);
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(R64_THREADS) void rank_f64_kernel(const double* __r
     bitonic_desc(key, id, n2);
     const int tot = have + take;
     have = tot < k ? tot : k;
+    c0 += take;
     __syncthreads();
   }
   for (int t = threadIdx.x; t < k; t += R64_THREADS) {

@@ -79,6 +79,7 @@ struct FusedArgs {
   float* inv_norm;
   int32_t* labels;
   unsigned int* queue;   // next image to hand out (initialised to the grid size)
+  unsigned long long* stamps;   // diagnostic build only: [16] cycle / event totals over all workgroups (pvs_fused_profile)
 };
 
 __device__ __forceinline__ float fu_power_norm(float v, float p) {
@@ -105,7 +106,10 @@ struct FuStage<PVS_DESC_U8_ROOTSIFT> {
 #define FU_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) \
   M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
 
-template <int KIND>
+// DIAG: s_memtime stamps of wave 0 around the phases (P0, A, reduce, re-evaluation, K2, epilogue, image switch) summed over
+// the workgroups into a.stamps[0..6], plus [8] stages, [9] stages with a re-evaluation, [10] entries, [11] rows not settled.
+// The product instantiation (DIAG = false) contains no stamp.
+template <int KIND, bool DIAG>
 __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const x32 = reinterpret_cast<float*>(smem + FU_OFF_X32);
@@ -146,6 +150,14 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
   FU_CASES(FU_ZERO)
 
   const float eps_a = 6.4e-5f * a.cmax, eps_b = 2.4e-5f * a.cmax * a.cmax;
+  unsigned long long dg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg_c[4] = {0, 0, 0, 0}, dg_last = 0;
+  if constexpr (DIAG) dg_last = __builtin_amdgcn_s_memtime();
+#define FU_STAMP(i)                                                  \
+  if constexpr (DIAG) {                                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+    dg_t[i] += now_ - dg_last;                                       \
+    dg_last = now_;                                                  \
+  }
 
   FuStage<KIND> stg;
   auto issue_loads = [&](int64_t rbase, int cnt) {   // rows rbase .. rbase + cnt - 1 of X -> registers (rows past cnt: zeros)
@@ -183,6 +195,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
       }
     };
     if (nst == 0) prefetch_next_image();
+    FU_STAMP(6)
 
     for (int64_t s = 0; s < nst; ++s) {
       const int64_t sbase = row0 + s * FU_R;
@@ -248,6 +261,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
         prefetch_next_image();
       }
       __syncthreads();
+      FU_STAMP(0)
 
       // ============================================================ A: scores of this wave's 32 clusters for all 64 rows
       {
@@ -325,6 +339,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
         scan(sc1, 1);
       }
       __syncthreads();
+      FU_STAMP(1)
 
       // ============================================================ B: labels (lane = row, every wave the same), exact re-evaluation, sums
       int label;
@@ -347,6 +362,8 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
         const bool settled = usable && label < a.K && (t1 - t2 > margin);
         const float thr = t1 - margin;
         const unsigned long long umask = __ballot(rvalid && !settled);
+        FU_STAMP(2)
+        if constexpr (DIAG) { dg_c[0] += 1; dg_c[3] += __popcll(umask); }
         if (umask != 0ull) {   // uniform over the workgroup: every wave reduced the same candidates
           // ---- entries: (row, wave) pairs whose best key is inside the margin; `all` when the wave's runner-up is too
           int cm = 0, am = 0;
@@ -371,6 +388,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
           }
           const int ebase = incl - ne;
           const int E = __shfl(incl, 63, 64);
+          if constexpr (DIAG) { dg_c[1] += 1; dg_c[2] += E; }
           if (wave == 0 && ne > 0) {
             int e = ebase;
             for (int w = 0; w < 8; ++w)
@@ -426,6 +444,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
             label = bv < INFINITY ? bk : 0;     // nothing below +inf: the exact kernel's initial label
           }
         }
+        FU_STAMP(3)
         if (a.labels != nullptr && wave == 0 && rvalid) a.labels[sbase + lane] = label;
 
         // ---- K2: this wave adds the rows of its clusters, in descriptor order; lane L owns dims 2L, 2L+1 of each cluster
@@ -459,6 +478,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
         }
       }
       __syncthreads();   // LDS is rewritten by the next stage's P0
+      FU_STAMP(4)
     }
 
     // ================================================================ E: K3 for this wave's 32 clusters, two clusters per pass
@@ -529,16 +549,26 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
       s2 = wave_sum_xor(s2, 64);
       if (lane == 0) a.inv_norm[cur] = s2 > 0.f ? 1.f / sqrtf(s2) : 1.f;
     }
+    FU_STAMP(5)
     cur = nxt;
     // (the next image's first barrier separates this image's s_rowsq / scratch reads from the next writes)
   }
+  if constexpr (DIAG) {
+    if (tid == 0 && a.stamps != nullptr) {
+      for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, dg_t[i]);
+      for (int i = 0; i < 4; ++i) atomicAdd(a.stamps + 8 + i, dg_c[i]);
+    }
+  }
+#undef FU_STAMP
 }
 
 __global__ void fused_queue_init_kernel(unsigned int* q, unsigned int v) { *q = v; }
 
 template <int KIND>
 static int launch_fused_kind(pvs_ctx* ctx, const FusedArgs& a, int grid) {
-  auto k = vlad_fused_kernel<KIND>;
+  auto kp = vlad_fused_kernel<KIND, false>;
+  auto kd = vlad_fused_kernel<KIND, true>;
+  auto k = a.stamps != nullptr ? kd : kp;
   PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(k), FU_LDS));
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(FU_THREADS), FU_LDS, ctx->stream, a);
   PVS_HIP(hipGetLastError());
@@ -570,8 +600,9 @@ int launch_vlad_fused(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, 
   a.norm_p = (float)ord;
   a.out = d_out; a.inv_norm = d_inv_norm; a.labels = d_labels;
   const int grid = (int)(n_images < ctx->num_cu ? n_images : ctx->num_cu);
-  if (ctx->d_queue == nullptr) PVS_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_queue), 256));
+  if (ctx->d_queue == nullptr) PVS_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_queue), 1024));
   a.queue = ctx->d_queue;
+  a.stamps = ctx->d_fused_stamps;
   ScopedTimer tm(ctx, T_ASSIGN);
   hipLaunchKernelGGL(fused_queue_init_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_queue, (unsigned int)grid);
   switch (kind) {

@@ -50,6 +50,17 @@ SIGNATURES = {
     "pvs_memcpy_h2d": [_vp, _vp, _vp, _sz],
     "pvs_memcpy_d2h": [_vp, _vp, _vp, _sz],
     "pvs_memset": [_vp, _vp, _int, _sz],
+    "pvs_fill_dev": [_vp, _vp, _i64, _int, C.c_uint64],
+    "pvs_stream_wait": [_vp, _vp],
+    "pvs_comm_unique_id": [_vp],
+    "pvs_comm_init": [_vp, _int, _int, _vp, _pp],
+    "pvs_comm_destroy": [_vp],
+    "pvs_comm_library": [],
+    "pvs_allgather_dev": [_vp, _vp, _vp, _sz],
+    "pvs_alltoall_dev": [_vp, _vp, _vp, _sz],
+    "pvs_sendrecv_dev": [_vp, _int, _vp, _vp, _vp, _vp, _vp],
+    "pvs_allreduce_max_f64": [_vp, _vp, _int],
+    "pvs_comm_barrier": [_vp],
     "pvs_codebook_create": [_vp, _vp, _int, _int, _pp],
     "pvs_codebook_destroy": [_vp, _vp],
     "pvs_gmm_create": [_vp, _vp, _vp, _vp, _int, _int, _pp],
@@ -84,6 +95,7 @@ SIGNATURES = {
     "pvs_seed_distances_dev": [_vp, _vp, _int, _i64, _vp, _int, _vp, _vp, _vp, _int],
     "pvs_seed_pick_dev": [_vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _int, _vp, _vp],
     "pvs_min_update_dev": [_vp, _vp, _vp, _i64, _vp],
+    "pvs_fused_profile": [_vp, _int, _vp],
     "pvs_timers_enable": [_vp, _int],
     "pvs_timers_reset": [_vp],
     "pvs_timers_read": [_vp, _int, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
@@ -148,6 +160,7 @@ def lib():
                     fn.argtypes = args
                     fn.restype = C.c_int
                 l.pvs_last_error.restype = C.c_char_p
+                l.pvs_comm_library.restype = C.c_char_p
                 l.pvs_stream.restype = C.c_void_p
                 _lib = l
     return _lib

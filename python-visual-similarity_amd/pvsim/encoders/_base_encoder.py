@@ -299,8 +299,47 @@ class ImageEncoderBase(SimilarityMetric):
             descs.append(fx.raw(image) if fused else fx(image))
         return descs, (DESC_F32_ROOTSIFT if fused else DESC_F32)
 
+    def _device_features(self, images):
+        """Extractors that keep their features on the GPU (`batch(images)` -> (B, n, D) float32 CUDA tensor, e.g.
+        DeepConvFeature) hand them to the encoder kernels as a device pointer: no per-image `.cpu().numpy()` round trip
+        (the reference copies every image's feature map to the host, features/_features.py:276-289)."""
+        fx = self.feature_extractor
+        dev = getattr(fx, "device", None)
+        if not hasattr(fx, "batch") or dev is None or getattr(dev, "type", "cpu") != "cuda":
+            return None
+        if _is_torch_tensor(images):
+            raise RuntimeError("Torch images are not supported yet.")
+        if isinstance(images, np.ndarray) and images.ndim == 3:
+            images = [images]
+        images = list(images)
+        if not images:
+            raise ValueError("need at least one array to concatenate")
+        import torch
+        if (dev.index or 0) != self.context.device:
+            return None
+        outs = []
+        for c0 in range(0, len(images), 64):
+            feats = fx.batch(images[c0:c0 + 64])
+            b, n, d = feats.shape
+            if d != self._input_dim:
+                raise RuntimeError(f"descriptor dimension {d} does not match the model input dimension {self._input_dim}")
+            if n == 0:
+                return None
+            offsets = (torch.arange(b + 1, dtype=torch.int64, device=feats.device) * n).contiguous()
+            torch.cuda.current_stream(feats.device).synchronize()      # the extractor ran on torch's stream
+            outs.append(self._encode_device(feats.data_ptr(), offsets.data_ptr(), b, b * n))
+        return np.vstack(outs)
+
+    def _encode_device(self, d_desc: int, d_offsets: int, n_images: int, total_desc: int) -> np.ndarray:
+        raise NotImplementedError
+
     def encode(self, images: Iterable[np.ndarray] | np.ndarray) -> np.ndarray:
         """(N, L) encodings of one image (H, W, 3) or an iterable of images."""
+        if hasattr(self.feature_extractor, "batch"):
+            images = [images] if isinstance(images, np.ndarray) and images.ndim == 3 else list(images)
+            out = self._device_features(images)
+            if out is not None:
+                return self._shape_output(out)
         descs, kind = self._gather_descriptors(images)
         if not descs:
             raise ValueError("need at least one array to concatenate")   # np.vstack([]) in the reference

@@ -10,6 +10,8 @@ from typing import Callable
 
 import numpy as np
 
+from ..engine import DESC_F32
+
 from ..features._features import FeatureExtractorBase, RootSIFT
 from .._utils import cosine_similarity
 from ._base_encoder import ImageEncoderBase
@@ -64,6 +66,18 @@ class FisherVectorEncoder(ImageEncoderBase):
         g, pca = self._device_tables()
         return self.context.fisher_encode(g, packed, offsets, kind, self.power_norm_weight, self.norm_order,
                                           self.epsilon, pca)
+
+    def _encode_device(self, d_desc, d_offsets, n_images, total_desc):
+        g, pca = self._device_tables()
+        ctx = self.context
+        L = g.K + 2 * g.K * g.D
+        buf = ctx.buffer(n_images * L * 8)
+        try:
+            ctx.fisher_encode_dev(g, d_desc, DESC_F32, d_offsets, n_images, total_desc, buf.ptr, 1, self.power_norm_weight,
+                                  self.norm_order, self.epsilon, pca)
+            return buf.download((n_images, L), np.float64)      # blocks until the result is on the host
+        finally:
+            buf.free()
 
     def _empty_quirk(self):
         raise ZeroDivisionError("an image without descriptors has no Fisher vector (reference divides by zero, "

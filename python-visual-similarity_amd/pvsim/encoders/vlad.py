@@ -8,6 +8,8 @@ from typing import Callable
 
 import numpy as np
 
+from ..engine import DESC_F32
+
 from ..features._features import FeatureExtractorBase, RootSIFT
 from .._utils import cosine_similarity
 from ._base_encoder import ImageEncoderBase
@@ -56,6 +58,18 @@ class VLADEncoder(ImageEncoderBase):
         cb, pca = self._device_tables()
         return self.context.vlad_encode(cb, packed, offsets, kind, self.power_norm_weight, self.norm_order,
                                         self.epsilon, pca)
+
+    def _encode_device(self, d_desc, d_offsets, n_images, total_desc):
+        cb, pca = self._device_tables()
+        ctx = self.context
+        L = cb.K * cb.D
+        buf = ctx.buffer(n_images * L * 4)
+        try:
+            ctx.vlad_encode_dev(cb, d_desc, DESC_F32, d_offsets, n_images, total_desc, buf.ptr, self.power_norm_weight,
+                                self.norm_order, self.epsilon, pca)
+            return buf.download((n_images, L), np.float32)
+        finally:
+            buf.free()
 
     def _shape_output(self, out):
         if self.flatten:

@@ -414,6 +414,13 @@ class Context:
         check(_ffi.lib().pvs_min_update_dev(self.handle, ptr(d_mind), ptr(d_dist), total_desc, ptr(bs)))
         return bs
 
+    def fused_profile(self, enable=True):
+        """pvs_fused_profile: (re)start or stop the stamped diagnostic build of the fused VLAD encode -> the 16 counters so far."""
+        out = np.zeros(16, dtype=np.int64)
+        check(_ffi.lib().pvs_fused_profile(self.handle, int(enable), ptr(out)))
+        names = ("P0", "A", "reduce", "reevaluate", "K2", "epilogue", "image_switch", "_", "stages", "stages_reevaluated", "entries", "rows_unsettled")
+        return {n: int(v) for n, v in zip(names, out) if n != "_"}
+
     # ------------------------------------------------------------------ timers
     def timers_enable(self, on=True):
         check(_ffi.lib().pvs_timers_enable(self.handle, int(on)))

@@ -1063,7 +1063,7 @@ def test_fused_encode_labels_equal_the_exact_kernel_on_many_rows(gpu_ctx, tables
     for pre in (0, 1):
         lab = torch.full((len(x),), -1, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
-        with gpu_ctx.option(_ffi.OPT_ASSIGN_PREFILTER, pre):
+        with gpu_ctx.option(_ffi.OPT_ASSIGN_PREFILTER, pre), gpu_ctx.option(_ffi.OPT_VLAD_PATH, _ffi.VLAD_PATH_FUSED if pre else _ffi.VLAD_PATH_GATHER):
             gpu_ctx.vlad_encode_dev(cb, d_x.data_ptr(), DESC_F32, d_off.data_ptr(), n_img, len(x), out.data_ptr(), d_labels=lab.data_ptr())
             gpu_ctx.sync()
         labs.append(lab.cpu().numpy())

@@ -265,3 +265,47 @@ def test_engine_and_torch_share_one_hip_runtime(order):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert [l for l in r.stdout.splitlines() if l.startswith("RUNTIMES")][-1].split()[1] == "1", r.stdout
+
+
+# ======================================================================================= deep features stay on the device
+def test_deep_features_reach_the_encoder_without_a_host_round_trip():
+    """FisherVectorEncoder / VLADEncoder .encode with a DeepConvFeature extractor: the (B, 196, D) feature tensor of
+    extractor.batch() is handed to pvs_fisher_encode_dev / pvs_vlad_encode_dev as a device pointer.  Equal (1e-12 / bit for
+    bit) to feeding the SAME features through the host entry point; against the per-image path (the reference's call
+    sequence) only up to the convolution's batch-size dependent rounding.  Extractor parity with torchvision's VGG16 is
+    unpinned (torchvision and its weights are absent offline; own `features` stack, random weights)."""
+    import torch
+    from pvsim.features import DeepConvFeature
+    from pvsim.encoders import FisherVectorEncoder, VLADEncoder
+    from pvsim.models import GMMModel, KMeansModel
+    torch.manual_seed(0)
+    fx = DeepConvFeature(spatial_encoding=False, device="cuda")
+    assert fx.output_dim == 512
+    rng = np.random.default_rng(4)
+    imgs = [rng.integers(0, 256, size=(80 + 8 * i, 100, 3), dtype=np.uint8) for i in range(5)]
+    K, D = 16, 512
+    gm = GMMModel(np.full(K, 1.0 / K), rng.normal(0, 0.05, (K, D)), rng.uniform(0.01, 0.05, (K, D)))
+    fenc = FisherVectorEncoder(fx, gmm_model=gm)
+    calls = []
+    orig = fx.__class__.__call__
+
+    def counting(self, image):
+        calls.append(1)
+        return orig(self, image)
+
+    fx.__class__.__call__ = counting
+    try:
+        f_dev = fenc.encode(imgs)
+    finally:
+        fx.__class__.__call__ = orig
+    assert not calls, "the per-image host path ran"
+    feats = fx.batch(imgs).cpu().numpy()
+    f_host = fenc.encode_descriptors([feats[i] for i in range(len(imgs))])
+    assert f_dev.dtype == np.float64 and f_dev.shape == (5, K + 2 * K * D)
+    np.testing.assert_allclose(f_dev, f_host, rtol=0, atol=1e-12)
+    f_each = np.vstack([fenc.encode_descriptors([fx(im)]) for im in imgs])
+    np.testing.assert_allclose(f_dev, f_each, rtol=0, atol=1e-5)
+    venc = VLADEncoder(fx, kmeans_model=KMeansModel(rng.normal(0, 0.05, (K, D)).astype(np.float32)))
+    v_dev = venc.encode(imgs)
+    v_host = venc.encode_descriptors([feats[i] for i in range(len(imgs))])
+    assert np.array_equal(v_dev, v_host)
