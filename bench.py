@@ -7,7 +7,7 @@
 
 One step = one pass of the hot path over the whole synthetic corpus, inputs already resident in HBM:
   encode  : descriptors -> KMeans assignment -> VLAD residual aggregation -> power + intra L2 norm
-  exchange: (N > 1) RCCL all-gather of the per-GPU encoding blocks
+  exchange: (N > 1) RCCL all-gather of the per-GPU encoding blocks (pvs_comm_* behind the C-ABI)
   retrieve: every image queries the whole corpus: N x N cosine GEMM + top-k (k = 5)
 Workload at 1 GPU = BASELINE.json configs[1]: 8189 images (Oxford-102 sized), ragged descriptor counts
 (LogNormal around 1257), D = 128, K = 256.  With N GPUs the same corpus is sharded by image
@@ -77,12 +77,14 @@ def parse():
     ap.add_argument("--images", type=int, default=8189)
     ap.add_argument("--desc", choices=["f32", "u8"], default="f32",
                     help="descriptor rows in HBM: fp32 RootSIFT (default) or raw uint8 SIFT with fused RootSIFT")
+    ap.add_argument("--queries", type=int, default=0, help="query rows per rank (0 = every local image: all-vs-all)")
+    ap.add_argument("--fused", action="store_true", help="encode with the one-read fused kernel (PVS_OPT_VLAD_PATH = 3) instead of assign + aggregate")
     ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim", "learn", "corpus1m"], default="config2",
                     help="config2 = the headline line (default).  Side workloads (single GPU, same JSON shape, not the "
                          "headline): fisher = BASELINE configs[2] (Fisher D=512 K=256 n=196), vlad512 = the per-GPU share of "
                          "configs[3] (n=512 descriptors per image, encode only), fp16sim = configs[4] scaled to one GPU "
                          "(N x N cosine on fp16 encodings + top-10)")
-    ap.add_argument("--retrieval", choices=["exact", "filtered"], default="exact",
+    ap.add_argument("--retrieval", choices=["exact", "filtered", "f16"], default="exact",
                     help="exact = f32 MFMA GEMM over all pairs (the headline). filtered = the same top-k lists, bit for bit, "
                          "through the fp16 prefilter + exact re-scoring (pvs_cosine_topk_filtered_dev); single GPU only. The "
                          "default run also times the filtered variant and reports it under 'filtered_retrieval'.")
@@ -202,6 +204,9 @@ def side_workload(args):
     elif args.workload == "vlad512":
         n = 512
         cb = ctx.codebook(tables["centroids"])
+        if args.fused:
+            from pvsim import _ffi
+            ctx.set_option(_ffi.OPT_VLAD_PATH, _ffi.VLAD_PATH_FUSED)
         from pvsim import synth
         proto = torch.from_numpy(synth.sift_prototypes().astype(np.float32)).to(dev)
         raw = torch.empty((N * n, DIM), dtype=torch.uint8, device=dev)
@@ -224,103 +229,15 @@ def side_workload(args):
         out.update({"metric": "images/sec VLAD-encoded, K256 D128 n512 (per-GPU share of BASELINE configs[3])",
                     "value": round(N / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "f32",
                     "scaling": "weak", "stages_ms_per_step": st,
-                    "config": {"workload": f"{N} images x 512 SIFT-like descriptors ({args.desc}), VLAD K=256 encode only"},
+                    "config": {"workload": f"{N} images x 512 SIFT-like descriptors ({args.desc}), VLAD K=256 encode only",
+                               "encode_path": "fused one-read kernel" if args.fused else "assign + aggregate"},
                     # the whole encode (assign + aggregate) against HBM: descriptors read twice (K1, K2) is what the kernels do,
                     # the algorithmic bytes count them once (393,216 B / image from f32 rows)
-                    "roofline": {"kernel": "assign16_kernel + assign_kernel (near ties) + vlad_aggregate_kernel", "bound": "hbm",
+                    "roofline": {"kernel": "vlad_fused_kernel (one read)" if args.fused else "assign16_kernel + assign_kernel (near ties) + vlad_aggregate_kernel", "bound": "hbm",
                                  "achieved": round(byt / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                  "frac": round(byt / dt / 1e9 / 8000.0, 4), "traffic": None,
-                                 "assign_executed_f16_TFLOPs": round(3 * 2.0 * N * n * K_CLUSTERS * DIM / (st["assign"] * 1e-3) / 1e12, 1)},
+                                 "assign_executed_f16_TFLOPs": None if args.fused else round(3 * 2.0 * N * n * K_CLUSTERS * DIM / (st["assign"] * 1e-3) / 1e12, 1)},
                     "encode_algorithmic_GBps": round(byt / dt / 1e9, 1)})
-    elif args.workload == "corpus1m":
-        # BASELINE configs[3]/[4] at their real size on ONE GPU: N images x 512 raw SIFT-like uint8 descriptors are generated
-        # on the device chunk by chunk, VLAD-encoded (fused RootSIFT) and kept as fp16 rows with fp32 1/||.|| (65.5 GB at
-        # N = 1e6: the corpus the 8-GPU configuration shards); then 8192 queries rank against the whole corpus (fp16 MFMA
-        # GEMM, fp32 accumulate, fused top-10).  One pass, no warm-up repetitions of the corpus build.
-        from pvsim import synth
-        n, k, L, CH = 512, 10, K_CLUSTERS * DIM, 16384
-        cb = ctx.codebook(tables["centroids"])
-        proto = torch.from_numpy(synth.sift_prototypes().astype(np.float32)).to(dev)
-        exact_mode = args.retrieval == "filtered"      # keep the fp32 corpus (4 bytes / element) and rank EXACTLY through the filter
-        db16 = None if exact_mode else torch.empty((N, L), dtype=torch.float16, device=dev)
-        db32 = torch.empty((N, L), dtype=torch.float32, device=dev) if exact_mode else None
-        inv = torch.empty((N,), dtype=torch.float32, device=dev)
-        enc = torch.empty((CH, L), dtype=torch.float32, device=dev)
-        off = (torch.arange(CH + 1, device=dev, dtype=torch.int64) * n).contiguous()
-        raw = torch.empty((CH * n, DIM), dtype=torch.uint8, device=dev)
-        ctx.timers_enable(True); ctx.timers_reset()
-        t_gen = t_enc = 0.0
-        for c0 in range(0, N, CH):
-            cn = min(CH, N - c0)
-            t0 = time.perf_counter()
-            for s0 in range(0, cn * n, 1 << 21):
-                e0 = min(cn * n, s0 + (1 << 21))
-                z = torch.randint(0, proto.shape[0], (e0 - s0,), generator=g, device=dev)
-                x = proto[z] * torch.exp(0.35 * torch.randn((e0 - s0, DIM), generator=g, device=dev)) + \
-                    4.8 * torch.rand((e0 - s0, DIM), generator=g, device=dev) ** 3
-                raw[s0:e0] = (x * (512.0 / x.norm(dim=1, keepdim=True).clamp_min(1e-9))).clamp_max(255.0).round().to(torch.uint8)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            ctx.vlad_encode_dev(cb, raw.data_ptr(), DESC_U8_ROOTSIFT, off.data_ptr(), cn, cn * n,
-                                (db32[c0:] if exact_mode else enc).data_ptr(), d_inv_norm=inv[c0:].data_ptr())
-            if not exact_mode:
-                ctx.f32_to_f16_dev(enc.data_ptr(), cn * L, db16[c0:].data_ptr())
-            ctx.sync()
-            t2 = time.perf_counter()
-            t_gen += t1 - t0
-            t_enc += t2 - t1
-            if (c0 // CH) % 8 == 0:
-                print(f"[corpus1m] {c0 + cn} / {N} images encoded", file=sys.stderr, flush=True)
-        tm_enc = ctx.timers()
-        nq = min(8192, N)
-        idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
-        val = torch.empty((nq, k), dtype=torch.float32, device=dev)
-        torch.cuda.synchronize()
-        ctx.timers_reset()
-        fst = None
-        if exact_mode:     # first call: the 2-byte workspace copy of the corpus is allocated (hipMalloc of N*L*2 bytes); timed apart
-            t0 = time.perf_counter()
-            ctx.cosine_topk_filtered_dev(db32.data_ptr(), nq, db32.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(), k,
-                                         idx.data_ptr(), val.data_ptr())
-            ctx.sync()
-            out["first_call_with_workspace_allocation_s"] = round(time.perf_counter() - t0, 3)
-            ctx.timers_reset()
-        t0 = time.perf_counter()
-        if exact_mode:
-            fst = ctx.cosine_topk_filtered_dev(db32.data_ptr(), nq, db32.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(), k,
-                                               idx.data_ptr(), val.data_ptr())
-        else:
-            ctx.cosine_topk_f16_dev(db16.data_ptr(), nq, db16.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(), k, 0, False,
-                                    idx.data_ptr(), val.data_ptr())
-        ctx.sync()
-        t_ret = time.perf_counter() - t0
-        tm_ret = ctx.timers(); ctx.timers_enable(False)
-        if exact_mode:
-            # the all-pairs f32 GEMM over the same corpus: must give the same lists, bit for bit
-            xi, xv = torch.empty_like(idx), torch.empty_like(val)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ctx.cosine_topk_dev(db32.data_ptr(), nq, db32.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(), k, 0, False,
-                                xi.data_ptr(), xv.data_ptr())
-            ctx.sync()
-            t_exact = time.perf_counter() - t0
-            same_lists = bool(torch.equal(xi, idx)) and bool(torch.equal(xv.view(torch.int32), val.view(torch.int32)))
-            assert same_lists, "filtered retrieval differs from the all-pairs f32 GEMM"
-            out["exact_check"] = {"all_pairs_f32_seconds": round(t_exact, 3), "lists_bit_identical": same_lists, "filter_stats": fst}
-        assert np.array_equal(idx[:, 0].cpu().numpy(), np.arange(nq)), "self-retrieval failed"
-        flop = 2.0 * nq * N * L
-        out.update({"metric": "images/sec VLAD-encoded into a resident fp16 corpus, then query rows/sec against it (BASELINE configs[3]/[4] on one GPU)",
-                    "value": round(N / t_enc, 1), "unit": "images/s", "ms_per_step": round(t_enc * 1e3, 1), "steps": 1, "warmup": 0,
-                    "dtype": "f32 encode, f16 retrieval operands", "scaling": "weak",
-                    "config": {"workload": f"{N} images x {n} uint8 descriptors -> {'fp32' if exact_mode else 'fp16'} corpus "
-                                           f"({N * L * (4 if exact_mode else 2) / 1e9:.1f} GB resident); "
-                                           f"{nq} queries x {N} rows, top-{k}"},
-                    "corpus_build": {"encode_s": round(t_enc, 3), "generate_s": round(t_gen, 1),
-                                     "stages_ms": {kk: round(v[0], 1) for kk, v in tm_enc.items() if v[1]}},
-                    "retrieval": {"seconds": round(t_ret, 3), "queries_per_s": round(nq / t_ret, 1),
-                                  "algorithmic_TFLOPs": round(flop / t_ret / 1e12, 1),
-                                  "stages_ms": {kk: round(v[0], 1) for kk, v in tm_ret.items() if v[1]}},
-                    "hbm_resident_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)})
     elif args.workload == "learn":
         # vocabulary training: one "step" = k-means++ seeding + 10 Lloyd iterations (K=256)
         # and 5 EM iterations of a K=256 diagonal GMM over args.images x 64 RootSIFT descriptors
@@ -399,331 +316,419 @@ def side_workload(args):
     ctx.close()
 
 
+class GlooStagedComm:
+    """REHEARSAL transport for a box with fewer GPUs than ranks: torch.distributed (gloo) with host-staged copies behind the
+    call contract of pvsim.distributed.RcclComm.  It exercises the whole multi-rank code path except the RCCL transport; its
+    numbers mean nothing.  The measured configuration is always RcclComm, one rank per GPU."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def all_gather(self, send, recv):
+        import torch
+        o = torch.empty(recv.shape, dtype=recv.dtype)
+        self.dist.all_gather_into_tensor(o, send.contiguous().cpu())
+        recv.copy_(o)
+
+    def all_to_all(self, out, inp):
+        import torch
+        o = torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_to_all_single(o, inp.cpu())
+        out.copy_(o)
+
+    def max_over_ranks(self, values):
+        import torch
+        t = torch.tensor(list(values), dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.numpy()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def rccl_unique_id(rank, world):
+    """The 128-byte communicator id of rank 0, handed over through the key-value store the launcher already runs
+    (torch.distributed.run exports MASTER_ADDR / MASTER_PORT; TORCHELASTIC_USE_AGENT_STORE says the agent hosts it)."""
+    from datetime import timedelta
+    import torch.distributed as dist
+    from pvsim import distributed as pd
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500"))
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+    store = dist.TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=timedelta(seconds=600))
+    key = "pvs_uid_" + os.environ.get("TORCHELASTIC_RUN_ID", "0") + "_" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    if rank == 0:
+        store.set(key, pd.new_unique_id())
+    return bytes(store.get(key)), store
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         return cpu_baseline_child(args.images)
-    if args.workload != "config2":
+    if args.workload not in ("config2", "corpus1m"):
         return side_workload(args)
+    corpus1m = args.workload == "corpus1m"
     cpu = None
-    if not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("PVS_BENCH_FORCE_DIST") != "1":
+    if (not corpus1m and not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1
+            and os.environ.get("PVS_BENCH_FORCE_DIST") != "1"):
         cpu = cpu_baseline_subprocess(args.images)      # before anything touches the GPU: the child forks worker processes
     import torch
-    import torch.distributed as dist
     import pvsim
+    from pvsim import distributed as pd
     from pvsim.engine import DESC_F32, DESC_U8_ROOTSIFT
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    # PVS_BENCH_BACKEND=gloo is a REHEARSAL mode for a box with fewer GPUs than ranks: ranks share the visible devices and
-    # the collectives go through host copies.  It exercises the whole multi-rank code path except the RCCL transport; its
-    # numbers mean nothing.  The measured configuration is always nccl (= RCCL), one rank per GPU.
-    backend = os.environ.get("PVS_BENCH_BACKEND", "nccl")
-    # PVS_BENCH_FORCE_DIST=1 (started through torch.distributed.run with ONE rank): the multi-rank code path -- process group, one
-    # stream shared with RCCL, asynchronous exchange, block-pair retrieval, list all-to-all -- on a single GPU; a self-check of
-    # that path against the plain single-GPU retrieval, not a measurement
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # PVS_BENCH_BACKEND=gloo: REHEARSAL (ranks share the visible GPUs, host-staged collectives, see GlooStagedComm)
+    backend = os.environ.get("PVS_BENCH_BACKEND", "rccl")
+    # PVS_BENCH_FORCE_DIST=1 (started through torch.distributed.run with ONE rank): the multi-rank code path -- RCCL communicator
+    # behind the C-ABI on its own stream, stream-ordered exchange, block-pair retrieval, list all-to-all -- on a single GPU: a
+    # self-check of that path against the plain single-GPU retrieval, not a measurement
     forced = os.environ.get("PVS_BENCH_FORCE_DIST") == "1" and world == 1
     multi = world > 1 or forced
     if backend == "gloo":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if multi:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    # PVS_BENCH_EXCHANGE=neighbours (experimental, default allgather): every rank receives only the blocks its share of the
-    # block-pair scheme reads -- (P-1)//2 full blocks plus, for even P, a full or half partner block -- by batched
-    # point-to-point transfers instead of the all-gather (-44 % bytes at P = 8)
-    exchange_mode = os.environ.get("PVS_BENCH_EXCHANGE", "allgather")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     overlap = os.environ.get("PVS_BENCH_OVERLAP", "1") != "0"      # exchange overlapped with the (r, r) block (RCCL only)
 
-    def coll(fn, out_t, in_t):
-        """out_t <- collective(in_t); through host copies in the gloo rehearsal mode"""
-        if backend == "gloo":
-            o = torch.empty(out_t.shape, dtype=out_t.dtype)
-            fn(o, in_t.cpu())
-            out_t.copy_(o)
-        else:
-            fn(out_t, in_t)
-
-    # N > 1: ONE stream for the engine, torch and (through torch's stream semantics) RCCL -- the step then needs no host
-    # synchronisation between encode, exchange and retrieval, and the CPU can run ahead of the many small launches
-    one_stream = multi
-    if one_stream:
+    # N > 1: the engine works on the stream torch allocates / fills on, so a step needs no host synchronisation between encode,
+    # scoring and merge; the exchange has a context (= stream) of its own, ordered against the compute stream by events
+    # (pvs_stream_wait), so the all-gather runs while the (r, r) block is scored
+    comm, ctx_x, store = None, None, None
+    if multi:
         side = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(side)
         ctx = pvsim.Context(local, stream=side.cuda_stream)
+        if backend == "gloo":
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+            comm = GlooStagedComm()
+        else:
+            ctx_x = pvsim.Context(local)
+            uid, store = rccl_unique_id(rank, world)
+            comm = pd.RcclComm(ctx_x, world, rank, uid)
     else:
         ctx = pvsim.Context(local)
+    staged = backend == "gloo"
     tables = np.load(os.path.join(REPO, "tests", "golden", "tables_k256_d128.npz"), allow_pickle=False)
     cb = ctx.codebook(tables["centroids"])
+    if args.fused:
+        from pvsim import _ffi
+        ctx.set_option(_ffi.OPT_VLAD_PATH, _ffi.VLAD_PATH_FUSED)
 
     # ---- corpus, sharded by image: rank r owns images [lo, hi)
     N = args.images
-    raw_all_counts_seed = 1235
     per = (N + world - 1) // world
     lo, hi = min(N, rank * per), min(N, (rank + 1) * per)
     n_loc = hi - lo
-    # every rank generates only its own shard (seeded per rank so shards differ)
-    raw, offsets = make_corpus(n_loc, raw_all_counts_seed + 7919 * rank, dev)
-    total_desc = int(offsets[-1])
-    kind = DESC_U8_ROOTSIFT if args.desc == "u8" else DESC_F32
-    desc = raw if args.desc == "u8" else rootsift_torch(raw)
-    d_off = torch.from_numpy(offsets).to(dev)
     L = K_CLUSTERS * DIM
+    k_top = 10 if corpus1m else TOPK
+    retr = args.retrieval
+    if retr == "f16" and not corpus1m:
+        raise SystemExit("--retrieval f16 belongs to --workload corpus1m (BASELINE configs[4])")
     enc_loc = torch.empty((per, L), dtype=torch.float32, device=dev)       # padded to the common block size
     inv_loc = torch.ones((per,), dtype=torch.float32, device=dev)
     if n_loc < per:
         enc_loc[n_loc:].zero_()
-    if multi:
-        enc_all = torch.empty((world * per, L), dtype=torch.float32, device=dev)
-        inv_all = torch.empty((world * per,), dtype=torch.float32, device=dev)
+    need_f32_all = multi and retr != "f16"
+    enc_all = torch.empty((world * per, L), dtype=torch.float32, device=dev) if need_f32_all else enc_loc
+    inv_all = torch.empty((world * per,), dtype=torch.float32, device=dev) if multi else inv_loc
+    enc16_loc = enc16_all = None
+    if retr == "f16":
+        enc16_loc = torch.empty((per, L), dtype=torch.float16, device=dev)
+        enc16_all = torch.empty((world * per, L), dtype=torch.float16, device=dev) if multi else enc16_loc
+    nq = n_loc if args.queries <= 0 else min(n_loc, args.queries)            # query rows of this rank (all of them by default)
+    idx = torch.empty((max(n_loc, 1), k_top), dtype=torch.int64, device=dev)
+    val = torch.empty((max(n_loc, 1), k_top), dtype=torch.float32, device=dev)
+
+    if corpus1m:
+        # BASELINE configs[3]: every image has 512 raw SIFT-like uint8 descriptors, generated on the device CHUNK BY CHUNK
+        # (the whole corpus of descriptors need not be resident: 65.5 GB at 1e6 images); a chunk is resident in HBM when
+        # its encode is timed, the generation itself is not part of the step
+        from pvsim import synth
+        n_desc, CH = 512, 16384
+        proto = torch.from_numpy(synth.sift_prototypes().astype(np.float32)).to(dev)
+        raw = torch.empty((CH * n_desc, DIM), dtype=torch.uint8, device=dev)
+        off = (torch.arange(CH + 1, device=dev, dtype=torch.int64) * n_desc).contiguous()
+        kind, total_desc = DESC_U8_ROOTSIFT, n_loc * n_desc
+        desc_bytes = total_desc * DIM
+
+        def encode_all():
+            """-> seconds spent encoding (generation excluded)"""
+            t_enc = 0.0
+            for c0 in range(0, n_loc, CH):
+                cn = min(CH, n_loc - c0)
+                g = torch.Generator(device=dev)
+                g.manual_seed(1237 + 100003 * (lo + c0))             # a chunk's content depends on its global position only
+                for s0 in range(0, cn * n_desc, 1 << 21):
+                    e0 = min(cn * n_desc, s0 + (1 << 21))
+                    z = torch.randint(0, proto.shape[0], (e0 - s0,), generator=g, device=dev)
+                    x = proto[z] * torch.exp(0.35 * torch.randn((e0 - s0, DIM), generator=g, device=dev)) + \
+                        4.8 * torch.rand((e0 - s0, DIM), generator=g, device=dev) ** 3
+                    raw[s0:e0] = (x * (512.0 / x.norm(dim=1, keepdim=True).clamp_min(1e-9))).clamp_max(255.0).round().to(torch.uint8)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.vlad_encode_dev(cb, raw.data_ptr(), kind, off.data_ptr(), cn, cn * n_desc, enc_loc[c0:].data_ptr(),
+                                    d_inv_norm=inv_loc[c0:].data_ptr())
+                if retr == "f16":
+                    ctx.f32_to_f16_dev(enc_loc[c0:].data_ptr(), cn * L, enc16_loc[c0:].data_ptr())
+                ctx.sync()
+                t_enc += time.perf_counter() - t0
+                if rank == 0 and (c0 // CH) % 16 == 0:
+                    print(f"[corpus1m] rank 0: {c0 + cn} / {n_loc} images encoded", file=sys.stderr, flush=True)
+            return t_enc
     else:
-        enc_all, inv_all = enc_loc, inv_loc
-    idx = torch.empty((max(n_loc, 1), TOPK), dtype=torch.int64, device=dev)
-    val = torch.empty((max(n_loc, 1), TOPK), dtype=torch.float32, device=dev)
+        # BASELINE configs[1]: ragged images, fp32 RootSIFT rows (or raw uint8) resident in HBM; every rank generates only its
+        # own shard (seeded per rank so shards differ)
+        raw, offsets = make_corpus(n_loc, 1235 + 7919 * rank, dev)
+        total_desc = int(offsets[-1])
+        kind = DESC_U8_ROOTSIFT if args.desc == "u8" else DESC_F32
+        desc = raw if args.desc == "u8" else rootsift_torch(raw)
+        d_off = torch.from_numpy(offsets).to(dev)
+        desc_bytes = total_desc * DIM * (1 if args.desc == "u8" else 4)
+
+        def encode_all():
+            ctx.vlad_encode_dev(cb, desc.data_ptr(), kind, d_off.data_ptr(), n_loc, total_desc, enc_loc.data_ptr(),
+                                d_inv_norm=inv_loc.data_ptr())
+            return None
     torch.cuda.synchronize()
 
-    from pvsim import distributed as pd
     score_block = pd.device_score_block(ctx)
-    ops = pd.DeviceOps(ctx, same_stream=one_stream)
+    ops = pd.DeviceOps(ctx, same_stream=multi)
+
+    def to_exchange_stream():
+        if ctx_x is not None:
+            ctx_x.wait_for(ctx)
+
+    def from_exchange_stream():
+        if ctx_x is not None:
+            ctx.wait_for(ctx_x)
 
     def a2a(out_t, in_t):
-        coll(dist.all_to_all_single, out_t, in_t)
-        if not one_stream:
-            torch.cuda.current_stream().synchronize()
+        to_exchange_stream()
+        comm.all_to_all(out_t, in_t)
+        from_exchange_stream()
 
     def new_tensor(shape, dtype, fill):
-        t_ = torch.full(shape, fill, dtype=dtype, device=dev)
-        if not one_stream:
-            torch.cuda.current_stream().synchronize()      # visible to the context's stream
-        return t_
-
-    def rows_of(r):
-        return max(0, min(N, (r + 1) * per) - r * per)
-
-    def exchange_neighbours():
-        P, B, h = world, per, (world - 1) // 2
-        sends, recvs = [], []                                   # (peer, row0, row1) of MY block / of the peer's block
-        for j in range(1, h + 1):
-            sends.append(((rank - j) % P, 0, n_loc))
-            recvs.append(((rank + j) % P, 0, rows_of((rank + j) % P)))
-        if P % 2 == 0:
-            pr = (rank + P // 2) % P
-            a, b = min(rank, pr), max(rank, pr)
-            hb = min(rows_of(b), (B + 1) // 2)
-            if rank == a:                                       # a scores Q_a x DB_b[0:hb]; b scores Q_a x DB_b[hb:]
-                sends.append((b, 0, n_loc))
-                recvs.append((b, 0, hb))
-            else:
-                sends.append((a, 0, hb))
-                recvs.append((a, 0, rows_of(a)))
-        enc_all[rank * B:rank * B + n_loc].copy_(enc_loc[:n_loc])
-        ops, stage = [], []
-        for peer, r0, r1 in sends:
-            if r1 > r0:
-                t_ = enc_loc[r0:r1]
-                if backend == "gloo":
-                    t_ = t_.cpu()
-                ops.append(dist.P2POp(dist.isend, t_, peer))
-        for peer, r0, r1 in recvs:
-            if r1 > r0:
-                dst = enc_all[peer * B + r0:peer * B + r1]
-                if backend == "gloo":
-                    buf = torch.empty(dst.shape, dtype=dst.dtype)
-                    stage.append((dst, buf))
-                    dst = buf
-                ops.append(dist.P2POp(dist.irecv, dst, peer))
-        works = dist.batch_isend_irecv(ops) if ops else []
-        if backend == "gloo" or not overlap:
-            for w_ in works:
-                w_.wait()
-            for dst, buf in stage:
-                dst.copy_(buf)
-            return []
-        return [w_.wait for w_ in works]
+        return torch.full(shape, fill, dtype=getattr(torch, dtype), device=dev)
 
     def exchange_begin():
-        """Start the exchange of the encoded blocks; returns the waiters to call before another rank's rows are read.  With RCCL
-        the collectives are asynchronous (they run on the process group's own stream after this stream's encode, and a waiter
-        only makes THIS stream wait for them), so the (r, r) block is scored while the blocks travel.  The gloo rehearsal
-        stages through the host and is synchronous."""
-        sync_mode = backend == "gloo" or not overlap
-        if exchange_mode == "neighbours":
-            ws = exchange_neighbours()
-        elif sync_mode:
-            coll(dist.all_gather_into_tensor, enc_all, enc_loc)
-            ws = []
+        """Start the exchange of the encoded blocks on the exchange stream (after the encode on the compute stream); returns the
+        call that makes the compute stream wait for it.  The gloo rehearsal stages through the host and is synchronous."""
+        to_exchange_stream()
+        if retr == "f16":
+            comm.all_gather(enc16_loc, enc16_all)
         else:
-            ws = [dist.all_gather_into_tensor(enc_all, enc_loc, async_op=True).wait]
-        if sync_mode:
-            coll(dist.all_gather_into_tensor, inv_all, inv_loc)
-        else:
-            ws.append(dist.all_gather_into_tensor(inv_all, inv_loc, async_op=True).wait)
-        return ws
+            comm.all_gather(enc_loc, enc_all)
+        comm.all_gather(inv_loc, inv_all)
+        if staged or not overlap:
+            from_exchange_stream()
+            return lambda: None
+        return from_exchange_stream
 
-    def step():
-        ctx.vlad_encode_dev(cb, desc.data_ptr(), kind, d_off.data_ptr(), n_loc, total_desc, enc_loc.data_ptr(),
-                            d_inv_norm=inv_loc.data_ptr())
-        waiters = []
-        if multi:
-            if not one_stream:
-                ctx.sync()                               # encode (ctx stream) -> collective (torch stream)
-            waiters = exchange_begin()
+    filt_stats = [None]
 
-        def exchanged():
-            for w_ in waiters:
-                w_()
-            if not one_stream:
-                torch.cuda.current_stream().synchronize()
-
-        if not multi and filtered[0]:
-            filt_stats[0] = ctx.cosine_topk_filtered_dev(enc_loc.data_ptr(), n_loc, enc_loc.data_ptr(), n_loc, L, inv_loc.data_ptr(),
-                                                         inv_loc.data_ptr(), TOPK, idx.data_ptr(), val.data_ptr())
-        elif not multi:
-            pd.retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, N, rank, world, TOPK, score_block, idx, val)
-        elif args.retrieval == "filtered":
+    def retrieve(filtered_now):
+        exchanged = exchange_begin() if multi else (lambda: None)
+        if retr == "f16":
             exchanged()
-            # opt-in: this rank's queries against the gathered corpus through the prefilter + exact re-scoring (no list
-            # exchange needed; the first N gathered rows are the real ones, padding only follows the last block)
-            ctx.cosine_topk_filtered_dev(enc_loc.data_ptr(), n_loc, enc_all.data_ptr(), N, L, inv_loc.data_ptr(), inv_all.data_ptr(),
-                                         TOPK, idx.data_ptr(), val.data_ptr())
+            ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_all.data_ptr(), N, L, inv_loc.data_ptr(), inv_all.data_ptr(), k_top,
+                                    0, False, idx.data_ptr(), val.data_ptr())
+        elif filtered_now:
+            exchanged()
+            # this rank's queries against the gathered corpus through the fp16 prefilter + exact re-scoring: the same lists as the
+            # exact path, no list exchange needed (the first N gathered rows are the real ones, padding only follows the last block)
+            filt_stats[0] = ctx.cosine_topk_filtered_dev(enc_loc.data_ptr(), nq, enc_all.data_ptr(), N, L, inv_loc.data_ptr(),
+                                                         inv_all.data_ptr(), k_top, idx.data_ptr(), val.data_ptr())
+        elif not multi:
+            ctx.cosine_topk_dev(enc_loc.data_ptr(), nq, enc_loc.data_ptr(), n_loc, L, inv_loc.data_ptr(), inv_loc.data_ptr(), k_top,
+                                0, False, idx.data_ptr(), val.data_ptr())
+        elif nq < n_loc:
+            exchanged()       # a query subset: plain row-block x all-blocks scoring (the pair scheme needs every rank's full block)
+            inv_m = inv_all.clone()
+            inv_m[N:] = float("nan")
+            ctx.cosine_topk_dev(enc_loc.data_ptr(), nq, enc_all.data_ptr(), world * per, L, inv_loc.data_ptr(), inv_m.data_ptr(), k_top,
+                                0, False, idx.data_ptr(), val.data_ptr())
         else:
-            # every block pair is scored once (dual-store GEMM), k-candidate lists exchanged, merged
-            # the (r, r) block reads the local copy, so it runs while the other blocks are still arriving
-            i_, v_ = pd.retrieve_symmetric(enc_all, inv_all, N, rank, world, TOPK, ops, a2a, new_tensor,
+            # every block pair is scored once (dual-store GEMM), k-candidate lists exchanged, merged; the (r, r) block reads
+            # the local copy, so it runs while the other blocks are still arriving
+            i_, v_ = pd.retrieve_symmetric(enc_all, inv_all, N, rank, world, k_top, ops, a2a, new_tensor,
                                            own=(enc_loc, inv_loc), before_cross=exchanged)
             idx[:n_loc].copy_(i_)
             val[:n_loc].copy_(v_)
 
     def barrier():
-        if multi:
-            dist.barrier()
+        if ctx_x is not None:
+            ctx_x.sync()
+        ctx.sync()
         torch.cuda.synchronize()
+        if multi:
+            comm.barrier()
 
-    def timed_steps():
+    def timed_steps(filtered_now):
+        t_enc_sum = 0.0
         for _ in range(args.warmup):
-            step()
+            encode_all()
+            retrieve(filtered_now)
         barrier()
         ctx.timers_enable(True)
         ctx.timers_reset()
         t0_ = time.perf_counter()
+        t_gen_excl = 0.0
         for _ in range(args.steps):
-            step()
+            ta = time.perf_counter()
+            te = encode_all()
+            tb = time.perf_counter()
+            if te is not None:                   # chunked corpus: only the encode part of the build counts
+                t_gen_excl += (tb - ta) - te
+                t_enc_sum += te
+            retrieve(filtered_now)
         barrier()
-        dt_ = time.perf_counter() - t0_
+        dt_ = time.perf_counter() - t0_ - t_gen_excl
         tm_ = ctx.timers()
         ctx.timers_enable(False)
-        return dt_, tm_
+        return dt_, tm_, t_enc_sum
 
-    filtered = [args.retrieval == "filtered" and not multi]   # (N > 1 reads args.retrieval directly in step())
-    filt_stats = [None]
+    filtered = retr == "filtered"
     other = None
-    if not multi:
+    if not multi and not corpus1m:
         # the variant that is NOT the headline of this run is timed first, its lists kept for the bit-for-bit comparison
-        filtered[0] = not filtered[0]
-        o_dt, o_tm = timed_steps()
-        other = {"dt": o_dt, "timers": o_tm, "idx": idx.clone(), "val": val.clone(), "was_filtered": filtered[0], "stats": filt_stats[0]}
-        filtered[0] = not filtered[0]
-    dt, timers = timed_steps()
+        o_dt, o_tm, _ = timed_steps(not filtered)
+        other = {"dt": o_dt, "timers": o_tm, "idx": idx.clone(), "val": val.clone(), "was_filtered": not filtered, "stats": filt_stats[0]}
+    dt, timers, t_enc_total = timed_steps(filtered)
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend != "gloo" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(comm.max_over_ranks([dt])[0])
     ms_per_step = dt / args.steps * 1e3
     value = N / (dt / args.steps)
 
     # ---- sanity inside the bench: self-retrieval must return the image itself first
-    got = idx[:n_loc, 0].cpu().numpy()
-    assert np.array_equal(got, np.arange(lo, hi)), "self-retrieval failed: top-1 is not the query image"
-    if multi and (backend == "gloo" or forced):
-        # rehearsal: the block-pair scheme must give exactly what one GPU gives for this rank's queries
-        ri = torch.empty((n_loc, TOPK), dtype=torch.int64, device=dev)
-        rv = torch.empty((n_loc, TOPK), dtype=torch.float32, device=dev)
-        inv_ref = inv_all.clone()
-        inv_ref[N:] = float("nan")                     # padding rows of the last block never rank
-        if exchange_mode == "neighbours":              # enc_all holds only this rank's partner blocks: gather everything for the check
-            coll(dist.all_gather_into_tensor, enc_all, enc_loc)
-        torch.cuda.synchronize()
-        ctx.cosine_topk_dev(enc_loc.data_ptr(), n_loc, enc_all.data_ptr(), min(world * per, enc_all.shape[0]), L, inv_loc.data_ptr(),
-                            inv_ref.data_ptr(), TOPK, 0, False, ri.data_ptr(), rv.data_ptr())
-        ctx.sync()
-        assert torch.equal(ri, idx[:n_loc]) and torch.equal(rv.view(torch.int32), val[:n_loc].view(torch.int32)), \
-            f"rank {rank}: multi-rank retrieval differs from the single-GPU ranking"
-        print(f"[rehearsal] rank {rank}: {n_loc} queries identical to the single-GPU ranking", file=sys.stderr)
+    got = idx[:nq, 0].cpu().numpy()
+    assert np.array_equal(got, np.arange(lo, lo + nq)), "self-retrieval failed: top-1 is not the query image"
+    check = None
+    if (multi and (staged or forced)) or (corpus1m and retr != "exact"):
+        # self-check: the multi-rank / filtered / fp16 result against the plain exact ranking of (a sample of) this rank's queries
+        nchk = nq if retr != "f16" and (staged or forced) else min(nq, 256)
+        ri = torch.empty((nchk, k_top), dtype=torch.int64, device=dev)
+        rv = torch.empty((nchk, k_top), dtype=torch.float32, device=dev)
+        barrier()
+        if multi and retr == "f16":
+            if staged or forced:             # the fp32 corpus was not gathered for the run: gather it now, for the check only
+                ref_db, ref_n = torch.empty((world * per, L), dtype=torch.float32, device=dev), world * per
+                torch.cuda.synchronize()
+                to_exchange_stream()
+                comm.all_gather(enc_loc, ref_db)
+                from_exchange_stream()
+                barrier()
+            else:
+                ref_db, ref_n = None, 0
+        else:
+            ref_db, ref_n = enc_all, (world * per if multi else n_loc)
+        if ref_db is not None:
+            inv_ref = inv_all.clone()
+            if multi:
+                inv_ref[N:] = float("nan")                     # padding rows of the last block never rank
+            torch.cuda.synchronize()
+            ctx.cosine_topk_dev(enc_loc.data_ptr(), nchk, ref_db.data_ptr(), ref_n, L, inv_loc.data_ptr(), inv_ref.data_ptr(), k_top,
+                                0, False, ri.data_ptr(), rv.data_ptr())
+            ctx.sync()
+            if retr == "f16":
+                a_, b_ = idx[:nchk].cpu().numpy(), ri.cpu().numpy()
+                recall = float(np.mean([len(set(a_[i]) & set(b_[i])) / k_top for i in range(nchk)]))
+                assert recall >= 0.99, f"fp16 retrieval recall@{k_top} = {recall:.4f} against the exact ranking"
+                check = {"fp16_recall_at_k_vs_exact_f32": round(recall, 5), "queries_checked": nchk}
+            else:
+                same = torch.equal(ri, idx[:nchk]) and torch.equal(rv.view(torch.int32), val[:nchk].view(torch.int32))
+                assert same, f"rank {rank}: retrieval differs from the plain exact ranking"
+                check = {"lists_bit_identical_to_plain_exact_ranking": True, "queries_checked": nchk}
+                print(f"[rehearsal] rank {rank}: {nchk} queries identical to the single-GPU ranking", file=sys.stderr)
+        else:
+            print(f"[rehearsal] rank {rank}: fp16 lists, no fp32 corpus gathered (self-retrieval checked)", file=sys.stderr)
 
     if rank != 0:
-        if multi:
-            dist.destroy_process_group()
+        if comm is not None:
+            comm.close()
         return
 
-    # ---- roofline of the dominant kernel (the cosine GEMM): EXECUTED flop / measured launch duration.
-    # One launch = local queries x one rank block.  When the block is the query block itself (self-similarity)
-    # the kernel computes only the upper triangle of 128x128 tiles and mirrors the rest, so the executed flop is
-    # ~half of the algorithmic 2*N*M*L of SURVEY.md section 8(d); `achieved` counts executed flop only (never above peak).
+    # ---- roofline of the dominant kernel (the similarity GEMM): EXECUTED flop / measured launch duration.
+    # Exact f32, single GPU or the pair scheme: the (r, r) block computes only the upper triangle of 128x128 tiles and mirrors
+    # the rest, so the executed flop is ~half of the algorithmic 2*N*M*L of SURVEY.md section 8(d); `achieved` counts executed
+    # flop only (never above peak).
     gemm_ms, gemm_n = timers["cosine_gemm"]
+    f16_gemm = retr in ("f16", "filtered")
     t128 = (n_loc + 127) // 128
-    if not multi:
-        alg_flop = 2.0 * N * N * L
-        flop_per_launch = 2.0 * 128 * 128 * L * (t128 * (t128 + 1) // 2)      # upper-triangle tiles
+    launches_per_step = max(gemm_n / max(args.steps, 1), 1.0)
+    if f16_gemm:
+        alg_flop = 2.0 * nq * N * L
+        flop_per_launch = alg_flop / launches_per_step          # panels of the fp16 GEMM (diagonal panels run symmetric: upper bound)
+    elif not multi:
+        alg_flop = 2.0 * nq * N * L
+        flop_per_launch = 2.0 * 128 * 128 * L * (t128 * (t128 + 1) // 2) if nq == n_loc else alg_flop
     else:
         alg_flop = 2.0 * n_loc * N * L
-        # symmetric pair scheme: own block (upper triangle) + (P-1)/2 cross blocks, over several launches per step
-        launches_per_step = max(gemm_n / max(args.steps, 1), 1.0)
         flop_per_launch = 2.0 * 128 * 128 * L * (t128 * (t128 + 1) / 2 + (world - 1) / 2.0 * t128 * t128) / launches_per_step
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flop_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
-    # the exact f32 GEMM only (the same process also runs the fp16 prefilter GEMM of the filtered variant)
-    traffic, traffic_src = pmc_traffic("pvs::gemm_mfma_kernel", keep=lambda nm: not _gemm_is_f16(nm))
-    if multi or N != 8189 or filtered[0]:
-        traffic, traffic_src = None, None             # the committed counters are for the default 1-GPU workload
+    peak = 2500.0 if f16_gemm else FP32_MFMA_PEAK_TFLOPS
+    default_line = not multi and not corpus1m and N == 8189 and not filtered
+    traffic, traffic_src = pmc_traffic("pvs::gemm_mfma_kernel", keep=lambda nm: not _gemm_is_f16(nm)) if default_line else (None, None)
     stages = {k: {"ms_total": round(v[0], 3), "launches": int(v[1]),
                   "ms_avg": round(v[0] / v[1], 4) if v[1] else None} for k, v in timers.items() if v[1]}
     enc_ms = (timers["assign"][0] + timers["aggregate"][0]) / args.steps
-    desc_bytes = total_desc * DIM * (1 if args.desc == "u8" else 4)
     enc_bytes = desc_bytes + n_loc * L * 4
+    workload = (f"configs[3]{'/[4]' if retr == 'f16' else ''}: {N} images x 512 uint8 SIFT-like descriptors (fused RootSIFT), VLAD K=256 encode"
+                f" (chunks of 16384 images, generation untimed) + {nq * world if multi else nq} x {N} cosine + top-{k_top}" if corpus1m else
+                f"configs[1]: {N} images x ragged SIFT-like descriptors (mean {total_desc / max(n_loc, 1):.0f}/image),"
+                f" D=128, VLAD K=256 encode + {N}x{N} cosine + top-{k_top}")
     out = {
         "metric": "images/sec encoded + top-k retrieved, VLAD K256 RootSIFT",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        **({"exchange": exchange_mode, "exchange_overlaps_own_block": bool(overlap and backend != "gloo")} if multi else {}),
+        **({"exchange": "allgather over " + ("gloo (host-staged REHEARSAL)" if staged else "RCCL behind the C-ABI (" + pd.RcclComm.library() + ")"),
+            "exchange_overlaps_own_block": bool(overlap and not staged and retr == "exact")} if multi else {}),
         **({"backend": "ONE-rank RCCL self-check of the multi-rank path: not a measurement"} if forced else {}),
-        **({"backend": "gloo REHEARSAL (ranks share GPUs, host-staged collectives): not a measurement"} if backend == "gloo" else {}),
+        **({"backend": "gloo REHEARSAL (ranks share GPUs, host-staged collectives): not a measurement"} if staged else {}),
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "retrieval": args.retrieval,
-        "config": {"workload": f"configs[1]: {N} images x ragged SIFT-like descriptors (mean {total_desc / max(n_loc, 1):.0f}/image),"
-                               f" D=128, VLAD K=256 encode + {N}x{N} cosine + top-{TOPK}",
-                   "images": N, "descriptors_rank0": total_desc, "descriptor_rows": args.desc,
-                   "K": K_CLUSTERS, "D": DIM, "topk": TOPK, "parallelism": f"image-sharded x{world}"},
-        "roofline": {"kernel": ("gemm_mfma_kernel<128,128,f16, chains of 1024 k> (prefilter GEMM of the filtered retrieval)" if filtered[0] else
+        "dtype": "f16" if retr == "f16" else "f32", "data": "synthetic", "retrieval": retr,
+        "config": {"workload": workload, "images": N, "descriptors_rank0": total_desc, "descriptor_rows": "u8" if corpus1m else args.desc,
+                   "K": K_CLUSTERS, "D": DIM, "topk": k_top, "parallelism": f"image-sharded x{world}",
+                   "encode_path": "fused one-read kernel" if args.fused else "assign + aggregate"},
+        "roofline": {"kernel": ("gemm_mfma_kernel<256,256,f16> (fp16 operands, fp32 accumulate)" if retr == "f16" else
+                                "gemm_mfma_kernel<128,128,f16, chains of 1024 k> (prefilter GEMM of the filtered retrieval)" if filtered else
                                 "gemm_mfma_kernel<128,128,f32> (cosine GEMM: main + split-K tail)"), "bound": "mfma", "achieved": round(achieved, 2),
-                     "peak": 2500.0 if filtered[0] else FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / (2500.0 if filtered[0] else FP32_MFMA_PEAK_TFLOPS), 4),
+                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flop_per_launch,
-                     "mfma_pipe_busy_frac": None if (multi or N != 8189 or filtered[0]) else
-                     pmc_mfma_busy("pvs::gemm_mfma_kernel", keep=lambda nm: not _gemm_is_f16(nm)),
+                     "mfma_pipe_busy_frac": pmc_mfma_busy("pvs::gemm_mfma_kernel", keep=lambda nm: not _gemm_is_f16(nm)) if default_line else None,
                      "algorithmic_flop_per_launch": alg_flop,
-                     "algorithmic_equiv_TFLOPs": round(alg_flop / (gemm_avg_ms * 1e-3) / 1e12, 2) if gemm_n else None, "avg_launch_ms": round(gemm_avg_ms, 4)},
+                     "algorithmic_equiv_TFLOPs": round(alg_flop / (gemm_avg_ms * launches_per_step * 1e-3) / 1e12, 2) if gemm_n else None,
+                     "avg_launch_ms": round(gemm_avg_ms, 4)},
         "stages": stages,
         "encode": {"ms_per_step": round(enc_ms, 3), "images_per_s": round(n_loc / (enc_ms * 1e-3), 1) if enc_ms else None,
                    "algorithmic_GBps": round(enc_bytes / (enc_ms * 1e-3) / 1e9, 1) if enc_ms else None,
+                   "hbm_roofline_frac": round(enc_bytes / (enc_ms * 1e-3) / 1e9 / 8000.0, 4) if enc_ms else None,
                    "assign_TFLOPs": round(2.0 * total_desc * K_CLUSTERS * DIM / (timers["assign"][0] / args.steps * 1e-3) / 1e12, 2)
                    if timers["assign"][0] else None},
         "device": ctx.device_name(),
     }
+    if corpus1m:
+        out["corpus_build"] = {"encode_s_per_step": round(t_enc_total / args.steps, 3), "resident_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
+    if check is not None:
+        out["self_check"] = check
+    if filt_stats[0] and (filtered or retr == "filtered"):
+        out["filter_stats"] = filt_stats[0]
 
     if other is not None:
         same_lists = bool(torch.equal(other["idx"], idx)) and bool(torch.equal(other["val"].view(torch.int32), val.view(torch.int32)))
         f_dt, f_tm, f_st = (other["dt"], other["timers"], other["stats"]) if other["was_filtered"] else (dt, timers, filt_stats[0])
         e_dt = dt if other["was_filtered"] else other["dt"]
-        out["retrieval"] = args.retrieval
         out["filtered_retrieval"] = {
             "what": "same top-k lists through pvs_cosine_topk_filtered_dev: fp16 MFMA prefilter with a proven error bound + exact "
                     "fp32 re-scoring of the candidates (bit-identical indices and scores; opt-in, --retrieval filtered)",
@@ -735,7 +740,7 @@ def main():
             "queries_redone_exact": f_st["redone_exact"] if f_st else None}
         assert same_lists, "filtered retrieval differs from the exact path"
 
-    if args.pcie and not multi:
+    if args.pcie and not multi and not corpus1m:
         h_desc = desc.cpu().numpy()
         t1 = time.perf_counter()
         v = ctx.vlad_encode(cb, h_desc, offsets, kind)
@@ -746,8 +751,8 @@ def main():
         out["cpu_baseline"] = cpu
 
     print(json.dumps(out))
-    if multi:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
 
 
 # ------------------------------------------------------------------------------------------------------------------

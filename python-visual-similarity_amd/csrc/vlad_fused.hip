@@ -46,7 +46,7 @@ constexpr int FU_XS = 132;          // floats per staged fp32 row (528 B: 16 row
 constexpr int FU_TS = 1056;         // bytes between the k-steps of a tile's fragment image (1024 + 32: spreads the P0 stores)
 constexpr int FU_TILE = 8 * FU_TS;  // one 32-row tile, hi or lo
 constexpr int FU_UNUSABLE = 0x7fffffff;
-constexpr int FU_KB = 4;            // rows of one wave added per batch in K2 (their loads are in flight together)
+constexpr int FU_KB = 8;            // rows of one wave added per batch in K2 (their loads are in flight together)
 
 constexpr int FU_OFF_X32 = 0;                              // float [64][132]
 constexpr int FU_OFF_XH = FU_OFF_X32 + FU_R * FU_XS * 4;   // fp16 fragments, hi: [2 tiles][8 k-steps][64 lanes][16 B]
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
         }
         if constexpr (DescTraits<KIND>::rootsift) {
           float sm = (x[0] + x[1]) + (x[2] + x[3]);    // integer-valued rows: the sum is exact in any order
-          sm = wave_sum_xor(sm, 32);
+          sm = half_sum_xor(sm);
           const RootsiftRow<KIND> rr(sm);
 #pragma unroll
           for (int q = 0; q < 4; ++q) x[q] = rr(x[q]);
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
           n2 = fmaf(x[q], x[q], n2);
           amax = fmaxf(amax, fabsf(x[q]));
         }
-        n2 = wave_sum_xor(n2, 32);
-        amax = wave_max_xor(amax, 32);
+        n2 = half_sum_xor(n2);
+        amax = half_max_xor(amax);
         const float nx = sqrtf(n2) * 1.0001f;
         int ex = 13;
         if (amax > 0.f) (void)frexpf(amax, &ex);
@@ -265,61 +265,54 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
 
       // ============================================================ A: scores of this wave's 32 clusters for all 64 rows
       {
-        f32x16 sc0, sc1;
+        // One 32-row tile after the other: 16 MFMAs for the small products (their partial sums stay small, so do their rounding
+        // errors), one for -|c|^2/2 2^(cs+xs) (three exact fp16 pieces of the table side times the row's power of two), 8 for ch.xh.
+        // Fragment reads run one k-step ahead of the MFMAs that use them; the fences let vector / scalar ALU work cross (the scan
+        // of tile 0 interleaves with the MFMAs of tile 1) but keep LDS reads and MFMAs in order -- hoisting ALL reads to the top
+        // would push the table and sum registers into scratch.
+        auto tile_scores = [&](int tile) -> f32x16 {
+          f32x16 sc;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { sc0[q] = 0.f; sc1[q] = 0.f; }
-        const char* fh = smem + FU_OFF_XH + lane * 16;
-        const char* fl = smem + FU_OFF_XL + lane * 16;
-        // fragment reads run one k-step ahead of the MFMAs that use them; the fences keep the scheduler from hoisting ALL reads
-        // to the top (16 live fragments per step would push the table and sum registers into scratch)
-        f16x8_t bh0 = *reinterpret_cast<const f16x8_t*>(fh), bl0 = *reinterpret_cast<const f16x8_t*>(fl);
-        f16x8_t bh1 = *reinterpret_cast<const f16x8_t*>(fh + FU_TILE), bl1 = *reinterpret_cast<const f16x8_t*>(fl + FU_TILE);
+          for (int q = 0; q < 16; ++q) sc[q] = 0.f;
+          const char* fh = smem + FU_OFF_XH + tile * FU_TILE + lane * 16;
+          const char* fl = smem + FU_OFF_XL + tile * FU_TILE + lane * 16;
+          f16x8_t bh = *reinterpret_cast<const f16x8_t*>(fh), bl = *reinterpret_cast<const f16x8_t*>(fl);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {   // the small products first: their partial sums stay small, so do their rounding errors
-          f16x8_t nh0 = bh0, nl0 = bl0, nh1 = bh1, nl1 = bl1;
-          if (t + 1 < 8) {
-            nh0 = *reinterpret_cast<const f16x8_t*>(fh + (t + 1) * FU_TS);
-            nl0 = *reinterpret_cast<const f16x8_t*>(fl + (t + 1) * FU_TS);
-            nh1 = *reinterpret_cast<const f16x8_t*>(fh + FU_TILE + (t + 1) * FU_TS);
-            nl1 = *reinterpret_cast<const f16x8_t*>(fl + FU_TILE + (t + 1) * FU_TS);
-          } else {
-            nh0 = *reinterpret_cast<const f16x8_t*>(fh);              // first k-step of the ch.xh pass
-            nh1 = *reinterpret_cast<const f16x8_t*>(fh + FU_TILE);
+          for (int t = 0; t < 8; ++t) {
+            f16x8_t nh, nl = bl;
+            if (t + 1 < 8) {
+              nh = *reinterpret_cast<const f16x8_t*>(fh + (t + 1) * FU_TS);
+              nl = *reinterpret_cast<const f16x8_t*>(fl + (t + 1) * FU_TS);
+            } else {
+              nh = *reinterpret_cast<const f16x8_t*>(fh);              // first k-step of the ch.xh pass
+            }
+            __builtin_amdgcn_sched_barrier(0x6);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tabl[t], bh, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tabh[t], bl, sc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x6);
+            bh = nh; bl = nl;
           }
-          __builtin_amdgcn_sched_barrier(0);
-          sc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tabl[t], bh0, sc0, 0, 0, 0);
-          sc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tabl[t], bh1, sc1, 0, 0, 0);
-          sc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tabh[t], bl0, sc0, 0, 0, 0);
-          sc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tabh[t], bl1, sc1, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          bh0 = nh0; bl0 = nl0; bh1 = nh1; bl1 = nl1;
-        }
-        {   // - |c|^2 / 2 . 2^(cs + xs): three exact fp16 pieces of the table side times the row's power of two
-          const int x0 = s_xsh[j], x1 = s_xsh[32 + j];
-          const _Float16 p0 = (h == 0 && x0 != FU_UNUSABLE) ? (_Float16)ldexpf(1.f, x0 + a.cn_e1) : (_Float16)0.f;
-          const _Float16 p1 = (h == 0 && x1 != FU_UNUSABLE) ? (_Float16)ldexpf(1.f, x1 + a.cn_e1) : (_Float16)0.f;
-          f16x8_t b0, b1;
+          {
+            const int xr = s_xsh[32 * tile + j];
+            const _Float16 pw = (h == 0 && xr != FU_UNUSABLE) ? (_Float16)ldexpf(1.f, xr + a.cn_e1) : (_Float16)0.f;
+            f16x8_t bb;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) { b0[q] = (_Float16)0.f; b1[q] = (_Float16)0.f; }
-          b0[0] = p0; b0[1] = p0; b0[2] = p0;
-          b1[0] = p1; b1[1] = p1; b1[2] = p1;
-          sc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cn_a, b0, sc0, 0, 0, 0);
-          sc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cn_a, b1, sc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          f16x8_t nh0 = bh0, nh1 = bh1;
-          if (t + 1 < 8) {
-            nh0 = *reinterpret_cast<const f16x8_t*>(fh + (t + 1) * FU_TS);
-            nh1 = *reinterpret_cast<const f16x8_t*>(fh + FU_TILE + (t + 1) * FU_TS);
+            for (int q = 0; q < 8; ++q) bb[q] = (_Float16)0.f;
+            bb[0] = pw; bb[1] = pw; bb[2] = pw;
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cn_a, bb, sc, 0, 0, 0);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          sc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tabh[t], bh0, sc0, 0, 0, 0);
-          sc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tabh[t], bh1, sc1, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          bh0 = nh0; bh1 = nh1;
-        }
-        // ---- scan: the lane holds, for row j of each tile, the scores of clusters (q & 3) + 8 (q >> 2) + 4 h of this wave
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            f16x8_t nh = bh;
+            if (t + 1 < 8) nh = *reinterpret_cast<const f16x8_t*>(fh + (t + 1) * FU_TS);
+            __builtin_amdgcn_sched_barrier(0x6);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tabh[t], bh, sc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x6);
+            bh = nh;
+          }
+          return sc;
+        };
+        // ---- scan: the lane holds, for row j of the tile, the scores of clusters (q & 3) + 8 (q >> 2) + 4 h of this wave
         auto scan = [&](const f32x16& sc, int tile) {
           float best = -INFINITY, second = -INFINITY;
 #pragma unroll
@@ -335,6 +328,8 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
           const float ns = fmaxf(fminf(best, ob), fmaxf(second, os));
           if (h == 0) s_cand[wave * FU_R + 32 * tile + j] = make_float2(nb, ns);
         };
+        const f32x16 sc0 = tile_scores(0);
+        const f32x16 sc1 = tile_scores(1);
         scan(sc0, 0);
         scan(sc1, 1);
       }
@@ -409,7 +404,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
             const float* xr = x32 + er * FU_XS;
             const float* cr = a.cpad + (size_t)k * 128;
             float dot = 0.f;
-#pragma unroll 2
+#pragma unroll 4
             for (int b8 = 0; b8 < 128; b8 += 8) {
               const float4 xa = *reinterpret_cast<const float4*>(xr + b8), xb = *reinterpret_cast<const float4*>(xr + b8 + 4);
               const float4 ca = *reinterpret_cast<const float4*>(cr + b8), cb = *reinterpret_cast<const float4*>(cr + b8 + 4);
@@ -506,7 +501,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
             const float tt = fu_norm_accum(v[q], a.norm_mode, a.norm_p);
             part = a.norm_mode == 3 ? fmaxf(part, tt) : part + tt;
           }
-          float nrm = a.norm_mode == 3 ? wave_max_xor(part, 32) : wave_sum_xor(part, 32);
+          float nrm = a.norm_mode == 3 ? half_max_xor(part) : half_sum_xor(part);   // the gather kernel's butterfly, bit for bit
           if (a.norm_mode == 2) nrm = sqrtf(nrm);
           else if (a.norm_mode == 0) nrm = powf(nrm, 1.f / a.norm_p);
           const float den = nrm + a.eps;
@@ -517,7 +512,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
             sq += o[q] * o[q];
           }
           if (k < a.K) *reinterpret_cast<float4*>(out_img + (int64_t)k * 128 + 4 * j) = make_float4(o[0], o[1], o[2], o[3]);
-          sq = wave_sum_xor(sq, 32);
+          sq = half_sum_xor(sq);
           if (j == 0 && k < a.K) s_rowsq[k] = sq;
         }
       };

@@ -1,24 +1,32 @@
-"""Multi-GPU path: one process per GPU, images sharded contiguously, ONE exchange (all-gather of the encoding
-blocks over RCCL/xGMI via torch.distributed), then every rank ranks its own query block against all blocks.
+"""Multi-GPU path: one process per GPU, images sharded contiguously, ONE exchange of the encoding blocks (RCCL over xGMI,
+behind the C-ABI: pvs_comm_* in include/pvsim.h), then every rank ranks its own query block against all blocks.
 
     rank r owns images [r*B, min(N, (r+1)*B)),  B = ceil(N / world)       (global index = r*B + local index,
                                                                            i.e. dict insertion order, eval.py:28)
 
-torch is plumbing here (device tensors + the collective).  The scoring itself is ONE C-ABI call
-`pvs_cosine_topk_dev` per rank (local queries x whole gathered corpus: a GEMM that fills the chip instead of
-`world` small ones).  Blocks have equal size B, so a row's position in the gathered array is its true global index;
-the trailing padding rows of the last block(s) carry a NaN inverse norm and therefore NaN scores, which the select
-kernel ranks last.  The logic is written against a `score_block` callable so that the same host code runs under
-`gloo` on CPU in tests/test_dist_gloo.py.
+Nothing here needs torch: device memory is pvs_malloc memory wrapped in `DevArray`, the collectives are `RcclComm`.  The
+retrieval logic only slices / indexes its array arguments along the first axis and asks them for `.data_ptr()`, so it runs
+unchanged on DevArrays, on torch CUDA tensors (bench.py generates its corpus with torch) and -- with CPU stand-ins for the
+device operations -- on torch CPU tensors under `gloo` (tests/test_dist_gloo.py).
+
+Blocks have equal size B, so a row's position in the gathered array is its true global index; the trailing padding rows of
+the last block(s) carry a NaN inverse norm and therefore NaN scores, which the select kernel ranks last.
 """
 from __future__ import annotations
 
+import ctypes as C
+import socket
+import struct
+import time
 from typing import Callable
 
 import numpy as np
 
 __all__ = ["shard_range", "gather_blocks", "mask_padding", "retrieve_sharded", "device_score_block",
-           "retrieve_symmetric", "symmetric_local", "symmetric_finish", "DeviceOps", "ShardedVLADIndex"]
+           "retrieve_symmetric", "symmetric_local", "symmetric_finish", "DeviceOps", "ShardedVLADIndex",
+           "DevArray", "DevicePool", "RcclComm", "new_unique_id", "exchange_unique_id"]
+
+_ITEM = {"float32": 4, "int64": 8, "int32": 4, "float64": 8, "float16": 2, "uint8": 1}
 
 
 def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int, int]:
@@ -28,16 +36,237 @@ def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int, int]:
     return lo, min(n_total, lo + block), block
 
 
-def gather_blocks(enc_loc, inv_loc, group=None):
-    """all_gather_into_tensor of the (block, L) encodings and (block,) inverse norms -> (world*block, L), (world*block,).
-    `enc_loc` must already be padded to the common block size (padding rows are ignored by retrieve_sharded)."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    enc_all = torch.empty((world * enc_loc.shape[0], enc_loc.shape[1]), dtype=enc_loc.dtype, device=enc_loc.device)
-    inv_all = torch.empty((world * inv_loc.shape[0],), dtype=inv_loc.dtype, device=inv_loc.device)
-    dist.all_gather_into_tensor(enc_all, enc_loc.contiguous(), group=group)
-    dist.all_gather_into_tensor(inv_all, inv_loc.contiguous(), group=group)
+# ------------------------------------------------------------------------------------------------------------------
+# device memory without torch
+class DevArray:
+    """A C-contiguous n-d view of device memory: first-axis indexing / slicing, reshape(-1), data_ptr() -- the subset of
+    the tensor protocol the retrieval logic uses."""
+
+    def __init__(self, ctx, ptr: int, shape, dtype: str, owner=None):
+        self.ctx, self.ptr, self.shape, self.dtype, self._owner = ctx, int(ptr), tuple(int(s) for s in shape), dtype, owner
+
+    @property
+    def itemsize(self) -> int:
+        return _ITEM[self.dtype]
+
+    @property
+    def nbytes(self) -> int:
+        return int(np.prod(self.shape, dtype=np.int64)) * self.itemsize
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+    def _row_bytes(self) -> int:
+        return int(np.prod(self.shape[1:], dtype=np.int64)) * self.itemsize
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            start, stop, step = key.indices(self.shape[0])
+            if step != 1:
+                raise IndexError("DevArray: unit stride only")
+            stop = max(stop, start)
+            return DevArray(self.ctx, self.ptr + start * self._row_bytes(), (stop - start,) + self.shape[1:], self.dtype, self)
+        i = int(key)
+        if i < 0:
+            i += self.shape[0]
+        if not 0 <= i < self.shape[0]:
+            raise IndexError("DevArray index out of range")
+        return DevArray(self.ctx, self.ptr + i * self._row_bytes(), self.shape[1:], self.dtype, self)
+
+    def reshape(self, *shape):
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else tuple(shape)
+        n = int(np.prod(self.shape, dtype=np.int64))
+        if shape.count(-1) > 1:
+            raise ValueError("DevArray.reshape: one -1 at most")
+        if -1 in shape:
+            known = int(np.prod([d for d in shape if d != -1], dtype=np.int64)) if len(shape) > 1 else 1
+            shape = tuple(n // max(known, 1) if d == -1 else int(d) for d in shape)
+        if int(np.prod(shape, dtype=np.int64)) != n:
+            raise ValueError("DevArray.reshape: size mismatch")
+        return DevArray(self.ctx, self.ptr, shape, self.dtype, self)
+
+    def fill(self, value):
+        n = int(np.prod(self.shape, dtype=np.int64))
+        if n:
+            self.ctx.fill_dev(self.ptr, n, self.dtype, value)
+        return self
+
+    def upload(self, a: np.ndarray):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.nbytes != self.nbytes:
+            raise ValueError("DevArray.upload: size mismatch")
+        from . import _ffi
+        _ffi.check(_ffi.lib().pvs_memcpy_h2d(self.ctx.handle, C.c_void_p(self.ptr), _ffi.ptr(a), a.nbytes))
+        return self
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            from . import _ffi
+            _ffi.check(_ffi.lib().pvs_memcpy_d2h(self.ctx.handle, _ffi.ptr(out), C.c_void_p(self.ptr), out.nbytes))
+        return out
+
+
+class DevicePool:
+    """Grow-only cache of pvs_malloc blocks keyed by size class.  Every user enqueues on the context's one stream, so a block
+    handed out again after release_all() is reused in stream order (hipMalloc / hipFree synchronise the device: never per step)."""
+
+    def __init__(self, ctx):
+        self.ctx, self._free, self._used = ctx, {}, []
+
+    def empty(self, shape, dtype: str) -> DevArray:
+        nbytes = max(int(np.prod(shape, dtype=np.int64)) * _ITEM[dtype], 16)
+        cls = 1 << (nbytes - 1).bit_length()
+        lst = self._free.setdefault(cls, [])
+        buf = lst.pop() if lst else self.ctx.buffer(cls)
+        self._used.append((cls, buf))
+        return DevArray(self.ctx, buf.ptr, shape, dtype, buf)
+
+    def full(self, shape, dtype: str, fill) -> DevArray:
+        return self.empty(shape, dtype).fill(fill)
+
+    def release_all(self):
+        for cls, buf in self._used:
+            self._free.setdefault(cls, []).append(buf)
+        self._used = []
+
+    def close(self):
+        self.release_all()
+        for lst in self._free.values():
+            for b in lst:
+                b.free()
+        self._free = {}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the exchange: RCCL behind the C-ABI
+def new_unique_id() -> bytes:
+    """pvs_comm_unique_id (rank 0): 128 bytes to hand to every rank by any host channel."""
+    from . import _ffi
+    buf = C.create_string_buffer(128)
+    _ffi.check(_ffi.lib().pvs_comm_unique_id(buf))
+    return buf.raw
+
+
+def exchange_unique_id(rank: int, world: int, addr: str, port: int, timeout: float = 300.0) -> bytes:
+    """A minimal host channel for the 128-byte id when nothing else is at hand: rank 0 listens on (addr, port) and serves
+    world - 1 connections; the others connect (retrying until rank 0 is up)."""
+    if world == 1:
+        return new_unique_id()
+    if rank == 0:
+        uid = new_unique_id()
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(struct.pack("<I", len(uid)) + uid)
+        return uid
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as s:
+                head = b""
+                while len(head) < 4:
+                    head += s.recv(4 - len(head))
+                n, = struct.unpack("<I", head)
+                data = b""
+                while len(data) < n:
+                    chunk = s.recv(n - len(data))
+                    if not chunk:
+                        raise ConnectionError("short read")
+                    data += chunk
+                return data
+        except (ConnectionError, OSError):
+            if time.time() > deadline:
+                raise
+            time.sleep(0.1)
+
+
+class RcclComm:
+    """One rank of the exchange, bound to a pvsim.Context (collectives are enqueued on that context's stream)."""
+
+    def __init__(self, ctx, world: int, rank: int, unique_id: bytes):
+        from . import _ffi
+        self.ctx, self.world, self.rank = ctx, int(world), int(rank)
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().pvs_comm_init(ctx.handle, self.world, self.rank, C.c_char_p(unique_id), C.byref(h)))
+        self.handle = h
+
+    @staticmethod
+    def library() -> str:
+        from . import _ffi
+        return (_ffi.lib().pvs_comm_library() or b"").decode()
+
+    def all_gather(self, send, recv, nbytes: int | None = None):
+        """recv[r] = rank r's `send` block; arrays with data_ptr() (and nbytes unless given) or raw pointers + nbytes."""
+        from . import _ffi
+        n = int(nbytes if nbytes is not None else _nbytes(send))
+        _ffi.check(_ffi.lib().pvs_allgather_dev(self.handle, _ffi.ptr(_dptr(send)), _ffi.ptr(_dptr(recv)), n))
+
+    def all_to_all(self, out, inp, nbytes_per_rank: int | None = None):
+        from . import _ffi
+        n = int(nbytes_per_rank if nbytes_per_rank is not None else _nbytes(inp) // self.world)
+        _ffi.check(_ffi.lib().pvs_alltoall_dev(self.handle, _ffi.ptr(_dptr(inp)), _ffi.ptr(_dptr(out)), n))
+
+    def send_recv(self, ops):
+        """ops: list of (peer, send_ptr | None, send_bytes, recv_ptr | None, recv_bytes) -- one batched point-to-point group."""
+        from . import _ffi
+        n = len(ops)
+        if not n:
+            return
+        peers = (C.c_int * n)(*[int(o[0]) for o in ops])
+        sp = (C.c_void_p * n)(*[C.c_void_p(int(o[1]) if o[1] else None) for o in ops])
+        sb = (C.c_size_t * n)(*[int(o[2]) for o in ops])
+        rp = (C.c_void_p * n)(*[C.c_void_p(int(o[3]) if o[3] else None) for o in ops])
+        rb = (C.c_size_t * n)(*[int(o[4]) for o in ops])
+        _ffi.check(_ffi.lib().pvs_sendrecv_dev(self.handle, n, peers, sp, sb, rp, rb))
+
+    def max_over_ranks(self, values) -> np.ndarray:
+        from . import _ffi
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy()
+        _ffi.check(_ffi.lib().pvs_allreduce_max_f64(self.handle, _ffi.ptr(v), v.shape[0]))
+        return v
+
+    def barrier(self):
+        from . import _ffi
+        _ffi.check(_ffi.lib().pvs_comm_barrier(self.handle))
+
+    def close(self):
+        if self.handle is not None:
+            from . import _ffi
+            _ffi.lib().pvs_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _dptr(a) -> int:
+    return int(a.data_ptr()) if hasattr(a, "data_ptr") else int(a)
+
+
+def _nbytes(a) -> int:
+    if hasattr(a, "nbytes"):
+        return int(a.nbytes)
+    return int(a.numel() * a.element_size())     # torch tensors
+
+
+def gather_blocks(enc_loc, inv_loc, comm, empty):
+    """All-gather of the (block, L) encodings and (block,) inverse norms -> (world*block, L), (world*block,).
+    `enc_loc` must already be padded to the common block size (padding rows are ignored by retrieve_sharded).
+    comm: RcclComm-like (all_gather(send, recv)); empty(shape, like) allocates a result array."""
+    world = comm.world
+    enc_all = empty((world * enc_loc.shape[0], enc_loc.shape[1]), enc_loc)
+    inv_all = empty((world * inv_loc.shape[0],), inv_loc)
+    comm.all_gather(enc_loc, enc_all)
+    comm.all_gather(inv_loc, inv_all)
     return enc_all, inv_all
 
 
@@ -47,7 +276,11 @@ def mask_padding(inv_loc, n_loc: int) -> None:
     displace a real image.  Because every block has the same size B and only trailing rows are padding, the row
     position in the gathered (world*B, L) array IS the true global image index."""
     if n_loc < inv_loc.shape[0]:
-        inv_loc[n_loc:] = float("nan")
+        tail = inv_loc[n_loc:]
+        if isinstance(tail, DevArray):
+            tail.fill(float("nan"))
+        else:
+            tail[...] = float("nan")
 
 
 def retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, n_total: int, rank: int, world: int, k: int,
@@ -68,7 +301,7 @@ def retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, n_total: int, rank: int
 
 
 def device_score_block(ctx):
-    """score_block for CUDA tensors: one pvs_cosine_topk_dev call (GEMM panel + select, running-list merge)."""
+    """score_block for device arrays: one pvs_cosine_topk_dev call (GEMM panel + select, running-list merge)."""
 
     def score(q, n_q, db, n_db, inv_q, inv_db, k, col_offset, merge, idx, val):
         ctx.cosine_topk_dev(q.data_ptr(), n_q, db.data_ptr(), n_db, q.shape[1], inv_q.data_ptr(), inv_db.data_ptr(),
@@ -96,9 +329,8 @@ class DeviceOps:
     """The four device operations of the scheme, bound to a pvsim.Context (tests plug in CPU stand-ins)."""
 
     def __init__(self, ctx, same_stream: bool = False):
-        """same_stream=True: the context was created on the stream the caller's tensors / collectives use (e.g.
-        pvsim.Context(dev, stream=torch.cuda.current_stream().cuda_stream)), so no host synchronisation is needed
-        between this object's launches and the caller's."""
+        """same_stream=True: the context was created on the stream the caller's arrays / collectives use, so no host
+        synchronisation is needed between this object's launches and the caller's."""
         self.ctx = ctx
         self.same_stream = same_stream
 
@@ -131,12 +363,12 @@ def retrieve_symmetric(enc_all, inv_all, n_total: int, rank: int, world: int, k:
     """Top-k of this rank's queries against the whole corpus, scoring each block pair once (see above).
 
     own = (enc_loc, inv_loc) and before_cross (a callable) let the exchange overlap the (r, r) block: that block is scored from
-    the rank's local copy, then before_cross() must make the gathered rows of the OTHER ranks visible (e.g. wait on the
-    asynchronous all-gather) before the cross blocks are scored.
+    the rank's local copy, then before_cross() must make the gathered rows of the OTHER ranks visible (e.g. make the compute
+    stream wait for the all-gather) before the cross blocks are scored.
 
     enc_all (world*B, L) / inv_all (world*B,): the gathered encodings and inverse norms (padding rows unused).
-    ops: DeviceOps-like.  all_to_all(out, inp): exchange of equal (B*k)-element slabs between ranks, e.g.
-    torch.distributed.all_to_all_single.  new_tensor(shape, dtype, fill): allocator on the right device.
+    ops: DeviceOps-like.  all_to_all(out, inp): exchange of equal (B*k)-element slabs between ranks (RcclComm.all_to_all).
+    new_tensor(shape, dtype, fill): allocator, dtype "int64" or "float32" (DevicePool.full).
     Returns (idx (n_loc, k) int64, val (n_loc, k) float32)."""
     st = symmetric_local(enc_all, inv_all, n_total, rank, world, k, ops, new_tensor, own=own, before_cross=before_cross)
     all_to_all(st["m_idx"][:world].reshape(-1), st["s_idx"].reshape(-1))
@@ -148,15 +380,14 @@ def symmetric_local(enc_all, inv_all, n_total: int, rank: int, world: int, k: in
                     before_cross=None) -> dict:
     """Phase 1 (no communication of its own): score this rank's block pairs; returns the send / merge buffers.
     own / before_cross: see retrieve_symmetric."""
-    import torch
     lo, hi, B = shard_range(n_total, world, rank)
     n_r = hi - lo
     P = world
     # slot p < P: list computed by rank p for my queries (received); slot P: what I computed for myself
-    m_idx = new_tensor((P + 1, B, k), torch.int64, -1)
-    m_val = new_tensor((P + 1, B, k), torch.float32, float("-inf"))
-    s_idx = new_tensor((P, B, k), torch.int64, -1)           # slot p: list I computed for rank p's queries
-    s_val = new_tensor((P, B, k), torch.float32, float("-inf"))
+    m_idx = new_tensor((P + 1, B, k), "int64", -1)
+    m_val = new_tensor((P + 1, B, k), "float32", float("-inf"))
+    s_idx = new_tensor((P, B, k), "int64", -1)           # slot p: list I computed for rank p's queries
+    s_val = new_tensor((P, B, k), "float32", float("-inf"))
     own_i, own_v = m_idx[P], m_val[P]
     blk = lambda t, r: t[r * B:(r + 1) * B]                  # noqa: E731
 
@@ -199,8 +430,8 @@ def symmetric_local(enc_all, inv_all, n_total: int, rank: int, world: int, k: in
             # short block inside a run would leave a gap -- runs therefore never extend past a short block
             span = (length - 1) * B + _rows(n_total, P, s0 + length - 1)
             assert span == n_cols, "a short block may only end a run"
-            panel = new_tensor((n_r, span), torch.float32, 0.0)
-            panel_t = new_tensor((span, n_r), torch.float32, 0.0)
+            panel = new_tensor((n_r, span), "float32", 0.0)
+            panel_t = new_tensor((span, n_r), "float32", 0.0)
             ops.dual(blk(enc_all, rank), n_r, enc_all[s0 * B:], span, blk(inv_all, rank), inv_all[s0 * B:], panel, panel_t)
             ops.topk(panel, n_r, span, k, s0 * B, True, own_i, own_v)                       # my queries
             for t in range(length):                                                         # partners' queries
@@ -216,8 +447,8 @@ def symmetric_local(enc_all, inv_all, n_total: int, rank: int, world: int, k: in
             c0, c1 = (0, hb) if rank == a else (hb, n_b)     # columns of the panel (= rows of block b) I compute
             if n_a > 0 and c1 > c0:
                 w = c1 - c0
-                panel = new_tensor((n_a, w), torch.float32, 0.0)
-                panel_t = new_tensor((w, n_a), torch.float32, 0.0)
+                panel = new_tensor((n_a, w), "float32", 0.0)
+                panel_t = new_tensor((w, n_a), "float32", 0.0)
                 ops.dual(blk(enc_all, a), n_a, enc_all[b * B + c0:], w, blk(inv_all, a), inv_all[b * B + c0:], panel, panel_t)
                 if rank == a:
                     ops.topk(panel, n_a, w, k, b * B + c0, True, own_i, own_v)              # my queries vs b[0:hb)
@@ -231,9 +462,8 @@ def symmetric_local(enc_all, inv_all, n_total: int, rank: int, world: int, k: in
 
 def symmetric_finish(st: dict, ops, new_tensor):
     """Phase 2 (after the all-to-all filled m_idx[:P] / m_val[:P]): merge the P received lists with the own list."""
-    import torch
-    out_i = new_tensor((st["B"], st["k"]), torch.int64, -1)
-    out_v = new_tensor((st["B"], st["k"]), torch.float32, float("-inf"))
+    out_i = new_tensor((st["B"], st["k"]), "int64", -1)
+    out_v = new_tensor((st["B"], st["k"]), "float32", float("-inf"))
     if st["n_r"] > 0:
         ops.merge(st["m_idx"], st["m_val"], st["P"] + 1, st["B"], st["k"], out_i, out_v)
         ops.sync()
@@ -241,48 +471,40 @@ def symmetric_finish(st: dict, ops, new_tensor):
 
 
 class ShardedVLADIndex:
-    """Encode this rank's images on its GPU, exchange once, answer all-vs-all top-k for the local block."""
+    """Encode this rank's images on its GPU, exchange once, answer all-vs-all top-k for the local block.  torch-free:
+    descriptors arrive as host arrays (or device pointers), the exchange is an RcclComm (None = single GPU)."""
 
-    def __init__(self, ctx, codebook, n_total: int, group=None):
-        import torch.distributed as dist
-        self.ctx, self.cb, self.n_total, self.group = ctx, codebook, n_total, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    def __init__(self, ctx, codebook, n_total: int, comm=None):
+        self.ctx, self.cb, self.n_total, self.comm = ctx, codebook, n_total, comm
+        self.world = comm.world if comm is not None else 1
+        self.rank = comm.rank if comm is not None else 0
         self.lo, self.hi, self.block = shard_range(n_total, self.world, self.rank)
+        self.pool = DevicePool(ctx)
 
-    def encode_local(self, d_desc, kind, d_offsets, total_desc, power=1.0, norm_order=2, epsilon=1e-9):
-        """d_desc / d_offsets: CUDA tensors holding this rank's packed descriptors and CSR offsets."""
-        import torch
+    def encode_local(self, d_desc: int, kind: int, d_offsets: int, total_desc: int, power=1.0, norm_order=2, epsilon=1e-9):
+        """d_desc / d_offsets: device pointers of this rank's packed descriptors and CSR offsets."""
         n_loc = self.hi - self.lo
         L = self.cb.K * self.cb.D
-        dev = d_desc.device
-        self.enc_loc = torch.zeros((self.block, L), dtype=torch.float32, device=dev)
-        self.inv_loc = torch.ones((self.block,), dtype=torch.float32, device=dev)
-        torch.cuda.synchronize(dev)
-        self.ctx.vlad_encode_dev(self.cb, d_desc.data_ptr(), kind, d_offsets.data_ptr(), n_loc, total_desc,
-                                 self.enc_loc.data_ptr(), power, norm_order, epsilon,
-                                 d_inv_norm=self.inv_loc.data_ptr())
-        self.ctx.sync()
+        self.enc_loc = self.pool.full((self.block, L), "float32", 0.0)
+        self.inv_loc = self.pool.full((self.block,), "float32", 1.0)
+        self.ctx.vlad_encode_dev(self.cb, d_desc, kind, d_offsets, n_loc, total_desc, self.enc_loc.ptr, power, norm_order,
+                                 epsilon, d_inv_norm=self.inv_loc.ptr)
         if self.world > 1:
             mask_padding(self.inv_loc, n_loc)
         return self.enc_loc
 
     def exchange(self):
         if self.world > 1:
-            self.enc_all, self.inv_all = gather_blocks(self.enc_loc, self.inv_loc, self.group)
-            import torch
-            torch.cuda.synchronize(self.enc_loc.device)
+            self.enc_all, self.inv_all = gather_blocks(self.enc_loc, self.inv_loc, self.comm,
+                                                       lambda shape, like: self.pool.empty(shape, like.dtype))
         else:
             self.enc_all, self.inv_all = self.enc_loc, self.inv_loc
 
     def topk(self, k: int):
-        import torch
         n_loc = self.hi - self.lo
-        dev = self.enc_loc.device
-        idx = torch.full((max(n_loc, 1), k), -1, dtype=torch.int64, device=dev)
-        val = torch.full((max(n_loc, 1), k), float("-inf"), dtype=torch.float32, device=dev)
-        torch.cuda.synchronize(dev)
+        idx = self.pool.full((max(n_loc, 1), k), "int64", -1)
+        val = self.pool.full((max(n_loc, 1), k), "float32", float("-inf"))
         retrieve_sharded(self.enc_loc, self.inv_loc, self.enc_all, self.inv_all, self.n_total, self.rank, self.world,
                          k, device_score_block(self.ctx), idx, val)
         self.ctx.sync()
-        return idx[:n_loc], val[:n_loc]
+        return idx[:n_loc].numpy(), val[:n_loc].numpy()

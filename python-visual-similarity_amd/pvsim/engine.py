@@ -167,6 +167,18 @@ class Context:
 
         return _Scoped()
 
+    def fill_dev(self, d_ptr: int, n_elems: int, dtype: str, value) -> None:
+        """4- or 8-byte pattern fill on this context's stream (dtype: float32 / int32 / int64 / float64)."""
+        a = np.array([value], dtype=dtype)
+        if a.itemsize not in (4, 8):
+            raise ValueError("fill_dev: 4- or 8-byte element types only")
+        pattern = int(a.view(np.uint32 if a.itemsize == 4 else np.uint64)[0])
+        check(_ffi.lib().pvs_fill_dev(self.handle, ptr(d_ptr), int(n_elems), a.itemsize, C.c_uint64(pattern)))
+
+    def wait_for(self, other: "Context") -> None:
+        """Work queued on THIS context after the call waits for everything `other` has queued so far (no host sync)."""
+        check(_ffi.lib().pvs_stream_wait(self.handle, other.handle))
+
     def device_name(self) -> str:
         buf = C.create_string_buffer(256)
         check(_ffi.lib().pvs_device_name(self.handle, buf, 256))

@@ -13,6 +13,27 @@ import torch.multiprocessing as mp
 from conftest import REPO
 
 
+class _GlooComm:
+    """torch.distributed (gloo) behind the call contract of pvsim.distributed.RcclComm -- CPU tensors."""
+
+    def __init__(self):
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def all_gather(self, send, recv):
+        dist.all_gather_into_tensor(recv, send.contiguous())
+
+    def all_to_all(self, out, inp):
+        dist.all_to_all_single(out, inp)
+
+
+def _empty_like(shape, like):
+    return torch.empty(shape, dtype=like.dtype)
+
+
+def _new_tensor(shape, dtype, fill):
+    return torch.full(shape, fill, dtype=getattr(torch, dtype))
+
+
 def _oracle_score_block(q, n_q, db, n_db, inv_q, inv_db, k, col_offset, merge, idx, val):
     import pvsim_oracle as orc
     s = orc.cosine_similarity(q[:n_q].numpy(), db[:n_db].numpy())
@@ -46,7 +67,7 @@ def _worker(rank, world, port, n_total, k, out_dir):
     enc_loc[: hi - lo] = torch.from_numpy(enc[lo:hi])
     inv_loc = torch.ones((block,), dtype=torch.float32)
     pd.mask_padding(inv_loc, hi - lo)
-    enc_all, inv_all = pd.gather_blocks(enc_loc, inv_loc)
+    enc_all, inv_all = pd.gather_blocks(enc_loc, inv_loc, _GlooComm(), _empty_like)
     assert enc_all.shape == (world * block, 48)
     idx = torch.full((block, k), -1, dtype=torch.int64)
     val = torch.full((block, k), float("-inf"), dtype=torch.float32)
@@ -140,10 +161,10 @@ def _sym_worker(rank, world, port, n_total, k, out_dir):
     enc_loc = torch.zeros((block, 40), dtype=torch.float32)
     enc_loc[: hi - lo] = torch.from_numpy(enc[lo:hi])
     inv_loc = torch.ones((block,), dtype=torch.float32)
-    enc_all, inv_all = pd.gather_blocks(enc_loc, inv_loc)             # real all_gather_into_tensor
-    idx, val = pd.retrieve_symmetric(enc_all, inv_all, n_total, rank, world, k, _CpuOps(),
-                                     lambda o, i: dist.all_to_all_single(o, i),   # real all-to-all
-                                     lambda shape, dtype, fill: torch.full(shape, fill, dtype=dtype))
+    comm = _GlooComm()
+    enc_all, inv_all = pd.gather_blocks(enc_loc, inv_loc, comm, _empty_like)     # real all_gather_into_tensor
+    idx, val = pd.retrieve_symmetric(enc_all, inv_all, n_total, rank, world, k, _CpuOps(), comm.all_to_all,   # real all-to-all
+                                     _new_tensor)
     np.savez(os.path.join(out_dir, f"s{rank}.npz"), idx=idx.numpy(), val=val.numpy(), enc=enc)
     dist.barrier()
     dist.destroy_process_group()
@@ -162,3 +183,35 @@ def test_symmetric_pair_scheme_gloo(tmp_path, world, n_total):
     ridx, rval = orc.topk(orc.cosine_similarity(enc, enc), k)
     assert np.array_equal(np.concatenate([p["idx"] for p in parts]), ridx)
     np.testing.assert_allclose(np.concatenate([p["val"] for p in parts]), rval, atol=1e-6)
+
+
+def test_devarray_views_and_unique_id_bootstrap():
+    """DevArray's first-axis views (the only tensor protocol the retrieval logic needs) and the socket hand-off of the
+    128-byte communicator id between two processes (no GPU: the id is replaced by a byte pattern)."""
+    import socket
+    import threading
+    from pvsim import distributed as pd
+    a = pd.DevArray(None, 1000, (3, 4, 5), "int64")
+    assert a[1].data_ptr() == 1000 + 160 and a[1].shape == (4, 5)
+    assert a[1:].shape == (2, 4, 5) and a[1:][0].data_ptr() == a[1].data_ptr()
+    assert a[2][1:].data_ptr() == 1000 + 2 * 160 + 40 and a[2][1:].shape == (3, 5)
+    assert a[:2].reshape(-1).shape == (40,) and a.reshape(-1).nbytes == 480
+    assert a[1:1].shape == (0, 4, 5)
+    with pytest.raises(IndexError):
+        a[3]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    uid = bytes(range(128))
+    orig = pd.new_unique_id
+    pd.new_unique_id = lambda: uid
+    got = {}
+    try:
+        ts = [threading.Thread(target=lambda r=r: got.__setitem__(r, pd.exchange_unique_id(r, 3, "127.0.0.1", port, 30.0))) for r in range(3)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(60)
+    finally:
+        pd.new_unique_id = orig
+    assert got == {0: uid, 1: uid, 2: uid}

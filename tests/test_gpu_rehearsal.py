@@ -1,57 +1,77 @@
-"""The multi-rank path of bench.py, rehearsed on ONE GPU (gloo, host-staged collectives).  Kept in its own file, collected
-after test_gpu_parity.py: these tests start subprocesses (torch.distributed.run), and a rendezvous hiccup here must not hide the
-kernel parity tests when the suite runs with -x."""
+"""The multi-rank path of bench.py on ONE GPU.  Kept in its own file, collected after the kernel parity tests: these tests start
+subprocesses (torch.distributed.run), and a rendezvous hiccup here must not hide the kernel parity tests when the suite runs with -x.
+
+  * REHEARSAL (PVS_BENCH_BACKEND=gloo): 2-4 ranks share this GPU, collectives staged through the host -- everything of the N > 1
+    run but the RCCL transport; every rank asserts that its lists equal the plain single-GPU ranking bit for bit.
+  * ONE-rank RCCL self-check (PVS_BENCH_FORCE_DIST=1): the same code path on the measured transport -- the RCCL communicator
+    behind the C-ABI (pvs_comm_*), on its own stream, ordered by events against the compute stream."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("ranks,exchange", [(2, "allgather"), (3, "neighbours"), (4, "neighbours")])
-def test_multi_rank_bench_rehearsal(ranks, exchange):
-    """bench.py's N > 1 path end to end with 2-4 ranks sharing this GPU (gloo, host-staged collectives): image sharding,
-    exchange, block-pair scoring, all-to-all of candidate lists, merge -- each rank asserts that its lists equal the
-    single-GPU ranking bit for bit.  Everything but the RCCL transport of the measured configuration."""
-    import json
-    import os
-    import socket
-    import subprocess
-    import sys
+def _run_bench(ranks, env_extra, extra_args, timeout=900):
     from conftest import REPO
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, PVS_BENCH_BACKEND="gloo", PVS_BENCH_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    if "PVS_BENCH_BACKEND" not in env_extra:
+        env.pop("PVS_BENCH_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1",
-           "--images", "1030", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(ranks), "--no-cpu-baseline"] + extra_args
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    return r, line
+
+
+@pytest.mark.parametrize("ranks,retrieval", [(2, "exact"), (3, "exact"), (4, "exact"), (2, "filtered")])
+def test_multi_rank_bench_rehearsal(ranks, retrieval):
+    """configs[1] (8189-image generator, reduced): image sharding, exchange, block-pair scoring (or the filtered retrieval against
+    the gathered corpus), all-to-all of candidate lists, merge."""
+    r, line = _run_bench(ranks, {"PVS_BENCH_BACKEND": "gloo"}, ["--steps", "1", "--warmup", "1", "--images", "1030", "--retrieval", retrieval])
     assert r.stderr.count("identical to the single-GPU ranking") == ranks, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == ranks and "REHEARSAL" in line["backend"] and line["exchange"] == exchange
+    assert line["n_gpus"] == ranks and "REHEARSAL" in line["backend"] and line["retrieval"] == retrieval
 
 
-@pytest.mark.parametrize("retrieval", ["exact", "filtered"])
-def test_one_rank_rccl_self_check(retrieval):
-    """The SAME multi-rank code path on the measured transport: one rank, backend nccl (= RCCL) -- process group bound to the
-    device, the engine on the stream RCCL synchronises with, the asynchronous all-gather overlapped with the (r, r) block,
-    the all-to-all of the candidate lists -- checked bit for bit against the plain single-GPU retrieval."""
-    import json
-    import os
-    import socket
-    import subprocess
-    import sys
+@pytest.mark.parametrize("ranks,retrieval", [(2, "exact"), (3, "filtered"), (2, "f16")])
+def test_sharded_corpus1m_rehearsal(ranks, retrieval):
+    """configs[3] / configs[4] (images x 512 uint8 descriptors generated and encoded chunk by chunk, every rank its block; all-vs-all
+    top-10), reduced to 20000 images: exact and filtered lists bit-identical to the plain ranking on every rank; fp16 lists
+    gathered as fp16 blocks, self-retrieval checked."""
+    r, line = _run_bench(ranks, {"PVS_BENCH_BACKEND": "gloo"},
+                         ["--workload", "corpus1m", "--steps", "1", "--warmup", "0", "--images", "20000", "--retrieval", retrieval])
+    if retrieval != "f16":
+        assert r.stderr.count("identical to the single-GPU ranking") == ranks, r.stderr[-3000:]
+    assert line["n_gpus"] == ranks and line["config"]["images"] == 20000 and "configs[3]" in line["config"]["workload"]
+
+
+@pytest.mark.parametrize("workload,retrieval", [("config2", "exact"), ("config2", "filtered"), ("corpus1m", "exact"), ("corpus1m", "f16")])
+def test_one_rank_rccl_self_check(workload, retrieval):
+    """One rank on RCCL through pvs_comm_init / pvs_allgather_dev / pvs_alltoall_dev: exchange stream + event ordering, the
+    all-gather overlapped with the (r, r) block, the list all-to-all -- against the plain single-GPU retrieval."""
+    args = ["--steps", "2", "--warmup", "1", "--retrieval", retrieval, "--workload", workload,
+            "--images", "1030" if workload == "config2" else "20000"]
+    r, line = _run_bench(1, {"PVS_BENCH_FORCE_DIST": "1"}, args)
+    if retrieval != "f16":
+        assert r.stderr.count("identical to the single-GPU ranking") == 1, r.stderr[-3000:]
+    else:
+        assert line["self_check"]["fp16_recall_at_k_vs_exact_f32"] >= 0.99
+    assert "RCCL self-check" in line["backend"] and "RCCL behind the C-ABI" in line["exchange"]
+
+
+def test_corpus1m_single_gpu_filtered_equals_exact():
+    """Single GPU, no launcher: the chunked corpus build + filtered retrieval, lists bit-identical to the all-pairs f32 GEMM."""
     from conftest import REPO
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, PVS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("PVS_BENCH_BACKEND", None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--images", "1030", "--no-cpu-baseline", "--retrieval", retrieval]
-    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "corpus1m", "--images", "30000", "--steps", "1",
+                        "--warmup", "0", "--retrieval", "filtered", "--queries", "2048"], cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert r.stderr.count("identical to the single-GPU ranking") == 1, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert "RCCL self-check" in line["backend"] and line["exchange_overlaps_own_block"] is True
+    assert line["self_check"]["lists_bit_identical_to_plain_exact_ranking"] is True and line["n_gpus"] == 1
