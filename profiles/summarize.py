@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Condense a gpurun_out/prof/ directory (rocprofv3 CSVs) into the small files committed under profiles/.
 
-    python profiles/summarize.py gpurun_out/prof r01
+    python profiles/summarize.py gpurun_out/prof r02                       # the headline run
+    python profiles/summarize.py gpurun_out/prof_vlad512 r02 vlad512 "bench.py --workload vlad512 ..."
 
 Expects <dir>/stats (rocprofv3 --kernel-trace --stats), <dir>/fetch (--pmc FETCH_SIZE) and <dir>/write
 (--pmc WRITE_SIZE) -- counters collected in their own passes, as the MI355X guide prescribes."""
 import collections, csv, glob, json, sys
 
 src, tag = sys.argv[1], sys.argv[2]
+name = sys.argv[3] if len(sys.argv) > 3 else ""
+command = sys.argv[4] if len(sys.argv) > 4 else "bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+stem = f"profiles/{tag}_{name}" if name else f"profiles/{tag}"
 
 
 def one(pattern):
@@ -18,7 +22,7 @@ def one(pattern):
 stats = one("stats/**/*_kernel_stats.csv")
 if stats:
     rows = list(csv.reader(open(stats)))
-    with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as f:
+    with open(f"{stem}_kernel_stats.csv", "w", newline="") as f:
         w = csv.writer(f)
         for r in rows:
             r[0] = r[0][:110]
@@ -52,9 +56,9 @@ if path:
         if d.get("SQ_BUSY_CU_CYCLES"):
             out.setdefault(k, {})["mfma_pipe_busy_frac"] = round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * d["SQ_BUSY_CU_CYCLES"]), 4)
 if out:
-    json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
-                          "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+    json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES (separate passes) "
+                          "--output-format csv -- python3 " + command,
                "note": "FETCH_SIZE doubled per the gfx950 correction; Infinity-Cache hits are included in these "
                        "fabric-side counters, so this is traffic beyond L2, an upper bound on HBM bytes",
-               "kernels": out}, open(f"profiles/{tag}_pmc_hbm.json", "w"), indent=1)
-print("wrote", glob.glob(f"profiles/{tag}_*"))
+               "kernels": out}, open(f"{stem}_pmc_hbm.json" if not name else f"{stem}_pmc.json", "w"), indent=1)
+print("wrote", glob.glob(f"{stem}_*"))

@@ -46,7 +46,7 @@ constexpr int FU_XS = 132;          // floats per staged fp32 row (528 B: 16 row
 constexpr int FU_TS = 1056;         // bytes between the k-steps of a tile's fragment image (1024 + 32: spreads the P0 stores)
 constexpr int FU_TILE = 8 * FU_TS;  // one 32-row tile, hi or lo
 constexpr int FU_UNUSABLE = 0x7fffffff;
-constexpr int FU_KB = 8;            // rows of one wave added per batch in K2 (their loads are in flight together)
+constexpr int FU_KB = 4;            // rows of one wave added per batch in K2 (their loads are in flight together)
 
 constexpr int FU_OFF_X32 = 0;                              // float [64][132]
 constexpr int FU_OFF_XH = FU_OFF_X32 + FU_R * FU_XS * 4;   // fp16 fragments, hi: [2 tiles][8 k-steps][64 lanes][16 B]
@@ -253,7 +253,9 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
           s_xsh[r] = usable ? xsh : FU_UNUSABLE;
         }
       }
-      // ---- request the next stage's rows (they land under phases A and B)
+      // ---- request the next stage's rows (they land under phases A and B).  Fenced: hoisted to the last use of each staging
+      // register, the requests would sit in front of this phase's remaining waits and expose a full HBM round trip per pass.
+      __builtin_amdgcn_sched_barrier(0);
       if (s + 1 < nst) {
         const int64_t left = n - (s + 1) * FU_R;
         issue_loads(sbase + FU_R, (int)(left < FU_R ? left : FU_R));
@@ -329,9 +331,11 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
           if (h == 0) s_cand[wave * FU_R + 32 * tile + j] = make_float2(nb, ns);
         };
         const f32x16 sc0 = tile_scores(0);
-        const f32x16 sc1 = tile_scores(1);
         scan(sc0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x16 sc1 = tile_scores(1);
         scan(sc1, 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
       FU_STAMP(1)
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
             const float* xr = x32 + er * FU_XS;
             const float* cr = a.cpad + (size_t)k * 128;
             float dot = 0.f;
-#pragma unroll 4
+#pragma unroll 2
             for (int b8 = 0; b8 < 128; b8 += 8) {
               const float4 xa = *reinterpret_cast<const float4*>(xr + b8), xb = *reinterpret_cast<const float4*>(xr + b8 + 4);
               const float4 ca = *reinterpret_cast<const float4*>(cr + b8), cb = *reinterpret_cast<const float4*>(cr + b8 + 4);
@@ -478,14 +482,17 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
 
     // ================================================================ E: K3 for this wave's 32 clusters, two clusters per pass
     {
-      float* const scr = x32 + wave * 1024;     // 4 KB per wave: 4 passes of 2 cluster rows (the stage buffers are idle here)
-      // pass p finishes clusters 2p (lanes 0..31) and 2p + 1 (lanes 32..63); four passes share one trip through the scratch rows
-      auto finish_round = [&](int p4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int p = 4 * p4 + u;
-          const int k = 32 * wave + 2 * p + h;
-          const float4 t = *reinterpret_cast<const float4*>(scr + u * 256 + h * 128 + 4 * j);
+      // 8 KB of scratch rows per wave (the stage buffers X32 | XH | XL are idle here and contiguous): two rounds of 16 clusters.
+      // The sums are written with literal register indices; the 8 passes of a round then run as a REAL loop over the LDS copy
+      // (unrolled 16 times, the normalisation -- with its inlined pow() for the general exponents -- was 37,000 instructions:
+      // instruction-cache misses and spilled store addresses made the epilogue the slowest phase).
+      float* const scr = x32 + wave * 2048;
+      // pass p of a round finishes clusters cbase + 2p (lanes 0..31) and cbase + 2p + 1 (lanes 32..63)
+      auto finish_round = [&](int cbase) {
+#pragma unroll 2
+        for (int p = 0; p < 8; ++p) {
+          const int k = 32 * wave + cbase + 2 * p + h;
+          const float4 t = *reinterpret_cast<const float4*>(scr + (2 * p + h) * 128 + 4 * j);
           float v[4] = {t.x, t.y, t.z, t.w};
           if (a.norm_mode == 4) {   // training pass: raw residual sums
             if (k < a.K) {
@@ -516,24 +523,16 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
           if (j == 0 && k < a.K) s_rowsq[k] = sq;
         }
       };
-#define FU_EW(u, p)                                                                                              \
-  *reinterpret_cast<float2*>(scr + (u) * 256 + 2 * lane) = make_float2(acc[4 * (p)], acc[4 * (p) + 1]);          \
-  *reinterpret_cast<float2*>(scr + (u) * 256 + 128 + 2 * lane) = make_float2(acc[4 * (p) + 2], acc[4 * (p) + 3]);
-      FU_EW(0, 0) FU_EW(1, 1) FU_EW(2, 2) FU_EW(3, 3)
+#define FU_EW(c) *reinterpret_cast<float2*>(scr + ((c) & 15) * 128 + 2 * lane) = make_float2(acc[2 * (c)], acc[2 * (c) + 1]);
+      FU_EW(0) FU_EW(1) FU_EW(2) FU_EW(3) FU_EW(4) FU_EW(5) FU_EW(6) FU_EW(7)
+      FU_EW(8) FU_EW(9) FU_EW(10) FU_EW(11) FU_EW(12) FU_EW(13) FU_EW(14) FU_EW(15)
       __builtin_amdgcn_wave_barrier();
       finish_round(0);
       __builtin_amdgcn_wave_barrier();
-      FU_EW(0, 4) FU_EW(1, 5) FU_EW(2, 6) FU_EW(3, 7)
+      FU_EW(16) FU_EW(17) FU_EW(18) FU_EW(19) FU_EW(20) FU_EW(21) FU_EW(22) FU_EW(23)
+      FU_EW(24) FU_EW(25) FU_EW(26) FU_EW(27) FU_EW(28) FU_EW(29) FU_EW(30) FU_EW(31)
       __builtin_amdgcn_wave_barrier();
-      finish_round(1);
-      __builtin_amdgcn_wave_barrier();
-      FU_EW(0, 8) FU_EW(1, 9) FU_EW(2, 10) FU_EW(3, 11)
-      __builtin_amdgcn_wave_barrier();
-      finish_round(2);
-      __builtin_amdgcn_wave_barrier();
-      FU_EW(0, 12) FU_EW(1, 13) FU_EW(2, 14) FU_EW(3, 15)
-      __builtin_amdgcn_wave_barrier();
-      finish_round(3);
+      finish_round(16);
 #undef FU_EW
       FU_CASES(FU_ZERO)
     }

@@ -16,6 +16,8 @@ dev = torch.device("cuda", 0)
 ctx = pvsim.Context(0)
 t = np.load(os.path.join(REPO, "tests", "golden", "tables_k256_d128.npz"), allow_pickle=False)
 cb = ctx.codebook(t["centroids"])
+from pvsim import _ffi
+two = {}
 g = torch.Generator(device=dev); g.manual_seed(1)
 proto = torch.from_numpy(synth.sift_prototypes().astype(np.float32)).to(dev)
 raw = torch.empty((N * n, 128), dtype=torch.uint8, device=dev)
@@ -38,12 +40,20 @@ ctx.sync()
 t0 = time.perf_counter()
 for _ in range(3): run()
 ctx.sync()
+two_kernel = (time.perf_counter() - t0) / 3
+ctx.set_option(_ffi.OPT_VLAD_PATH, _ffi.VLAD_PATH_FUSED)
+for _ in range(2): run()
+ctx.sync()
+t0 = time.perf_counter()
+for _ in range(3): run()
+ctx.sync()
 plain = (time.perf_counter() - t0) / 3
 ctx.fused_profile(True)
 run(); ctx.sync()
 st = ctx.fused_profile(False)
 tot = sum(st[k] for k in ("P0", "A", "reduce", "reevaluate", "K2", "epilogue", "image_switch"))
 out = {"images": N, "kind": "u8" if u8 else "f32", "ms_per_pass": round(plain * 1e3, 3), "images_per_s": round(N / plain, 1),
+       "two_kernel_ms_per_pass": round(two_kernel * 1e3, 3), "two_kernel_images_per_s": round(N / two_kernel, 1),
        "cycles_per_stage": {k: round(st[k] / max(st["stages"], 1), 1) for k in ("P0", "A", "reduce", "reevaluate", "K2", "epilogue", "image_switch")},
        "share": {k: round(st[k] / tot, 3) for k in ("P0", "A", "reduce", "reevaluate", "K2", "epilogue", "image_switch")},
        "stages": st["stages"], "stages_reevaluated_frac": round(st["stages_reevaluated"] / max(st["stages"], 1), 3),
