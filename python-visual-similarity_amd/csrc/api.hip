@@ -317,22 +317,16 @@ PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, 
     if (hipMalloc(&cb->d_c16, h16.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
     else if (hipMemcpyAsync(cb->d_c16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
     if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;   // h16 goes out of scope
-    // tables of the fused encode (vlad_fused.hip): natural dim order, and -|c|^2/2 as three exact fp16 pieces
-    if (st == PVS_OK && cb->K_pad == 256 && D == 128) {
-      std::vector<_Float16> n16((size_t)2 * 256 * 128, (_Float16)0.f), pk((size_t)256 * 4, (_Float16)0.f);
+    // -|c|^2/2 as three exact fp16 pieces per cluster (the prefilter adds it on the matrix pipe, vlad.hip / vlad_fused.hip)
+    if (st == PVS_OK) {
+      std::vector<_Float16> pk((size_t)cb->K_pad * 4, (_Float16)0.f);
       float amaxa = 0.f;
       for (int k = 0; k < K; ++k) amaxa = std::max(amaxa, std::fabs(std::ldexp(-0.5f * cn[k], cb->c16_shift)));
       int ea = 0;
       (void)std::frexp(amaxa, &ea);
       cb->cn_e1 = ea - 13;
-      for (int k = 0; k < 256; ++k) {
+      for (int k = 0; k < cb->K_pad; ++k) {
         if (k < K) {
-          for (int d = 0; d < 128; ++d) {
-            const float v = centroids[(size_t)k * D + d] * sc;
-            const _Float16 hi = (_Float16)v;
-            n16[(size_t)k * 128 + d] = hi;
-            n16[(size_t)256 * 128 + (size_t)k * 128 + d] = (_Float16)(v - (float)hi);
-          }
           const float av = std::ldexp(-0.5f * cn[k], cb->c16_shift - cb->cn_e1);   // exact: powers of two
           const _Float16 p1 = (_Float16)av;
           const float r1 = av - (float)p1;
@@ -343,12 +337,26 @@ PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, 
           pk[(size_t)k * 4 + 0] = (_Float16)(-65504.f);   // below every real score of a row the prefilter takes
         }
       }
-      if (std::isfinite(amaxa) && amaxa > 0.f) {
-        if (hipMalloc(&cb->d_c16n, n16.size() * 2) != hipSuccess || hipMalloc(&cb->d_cnk, pk.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
-        else if (hipMemcpyAsync(cb->d_c16n, n16.data(), n16.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                 hipMemcpyAsync(cb->d_cnk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
-        if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
-      }
+      if (!(std::isfinite(amaxa) && amaxa > 0.f)) {       // degenerate table: no prefilter at all
+        hipFree(cb->d_c16);
+        cb->d_c16 = nullptr;
+      } else if (hipMalloc(&cb->d_cnk, pk.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
+      else if (hipMemcpyAsync(cb->d_cnk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
+      if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
+    }
+    // the fp16 tables once more in natural dim order for the fused encode (vlad_fused.hip: K_pad == 256 and D == 128 only)
+    if (st == PVS_OK && cb->d_c16 != nullptr && cb->K_pad == 256 && D == 128) {
+      std::vector<_Float16> n16((size_t)2 * 256 * 128, (_Float16)0.f);
+      for (int k = 0; k < K; ++k)
+        for (int d = 0; d < 128; ++d) {
+          const float v = centroids[(size_t)k * D + d] * sc;
+          const _Float16 hi = (_Float16)v;
+          n16[(size_t)k * 128 + d] = hi;
+          n16[(size_t)256 * 128 + (size_t)k * 128 + d] = (_Float16)(v - (float)hi);
+        }
+      if (hipMalloc(&cb->d_c16n, n16.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
+      else if (hipMemcpyAsync(cb->d_c16n, n16.data(), n16.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
+      if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
     }
   }
   if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;

@@ -95,9 +95,9 @@ struct pvs_codebook {
   int D_pad16 = 0;           // multiple of 16
   int c16_shift = 0;         // the largest |c| 2^shift lies in [2^12, 2^13)
   float cmax = 0.f;          // max_k ||c_k||_2
+  void* d_cnk = nullptr;     // [K_pad][4] _Float16: three pieces of -|c|^2/2 2^(c16_shift - cn_e1) (padded clusters: -65504, 0, 0), 0
   // tables of the fused encode (vlad_fused.hip; K_pad == 256 and D == 128 only)
   void* d_c16n = nullptr;    // [2][256][128] _Float16: the same hi | lo values in natural dim order, zero rows for padded clusters
-  void* d_cnk = nullptr;     // [256][4] _Float16: three pieces of -|c|^2/2 2^(c16_shift - cn_e1) (padded clusters: -65504, 0, 0), 0
   int cn_e1 = 0;             // the largest |c|^2/2 2^(c16_shift - cn_e1) lies in [2^12, 2^13)
 };
 

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign_kernel(AssignArgs a)
 //                       + 128 2^-24 (the exact kernel's own accumulation) + 1e-9 (flush below the fp16 normal range) ] |x||c|
 //   eps = 2 |dot16 - dot32| + 2^-22 (|c|^2 + 2 |x||c|)   (the final fma of both kernels)
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 struct Assign16Args {
   const void* X;
@@ -203,6 +204,8 @@ struct Assign16Args {
   int K_pad, D_pad16;
   int c_shift;
   float cmax;
+  const _Float16* cnk;  // [K_pad][4]: three exact fp16 pieces of -|c|^2/2 2^(c_shift - cn_e1) (padded clusters: -65504, 0, 0), 0
+  int cn_e1, K;
   int32_t* labels;
   int64_t* amb_rows;             // [gridDim][cap]: descriptors left to the exact kernel, one list per workgroup
   unsigned long long* amb_count; // [gridDim]
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
   _Float16* lds_h = reinterpret_cast<_Float16*>(smem);
   _Float16* lds_l = lds_h + CB * stride;
   float* lds_n = reinterpret_cast<float*>(lds_l + CB * stride);
+  _Float16* lds_k = reinterpret_cast<_Float16*>(lds_n + CB);    // [CB][4]: the -|c|^2/2 pieces (STEPS > 0 only)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int nt = a.D_pad16 >> 4;      // k-steps of 16 dims
@@ -232,6 +236,9 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
     *reinterpret_cast<uint4*>(lds_h + r * stride + 8 * c8) = *reinterpret_cast<const uint4*>(a.C16 + (int64_t)r * a.D_pad16 + 8 * c8);
   }
   for (int idx = threadIdx.x; idx < CB; idx += ASSIGN_THREADS) lds_n[idx] = a.cnorm[idx];
+  if constexpr (STEPS > 0)
+    for (int idx = threadIdx.x; idx < CB; idx += ASSIGN_THREADS)
+      *reinterpret_cast<uint2*>(lds_k + 4 * idx) = *reinterpret_cast<const uint2*>(a.cnk + 4 * idx);
   if (threadIdx.x == 0) s_count = 0u;
   __syncthreads();
   const float sqrt_d = sqrtf((float)a.D);
@@ -317,6 +324,9 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
     int x_shift = 13 - ex;
     bool finite = nx <= 3.0e38f;   // false for NaN too
     if (x_shift > 40 || x_shift < -40) { finite = false; x_shift = 0; }
+    if constexpr (STEPS > 0) {     // the row scale enters the -|c|^2/2 step as an fp16 factor: it must be a normal fp16 number
+      if (x_shift + a.cn_e1 < -14 || x_shift + a.cn_e1 > 15) finite = false;
+    }
     const float xs = ldexpf(1.f, x_shift);
     f16x8_t xh[8], xl[8];
 #pragma unroll
@@ -343,13 +353,6 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
       constexpr int NG = NT / G2;
       f32x16 acc[2][G2];
       f16x8_t fh[2][G2], fl[2][G2];
-      float4 cnb;                             // the table norms of the NEXT step's selection part, read at the end of a step
-      int nh = 4 * h;
-      asm volatile("" : "+v"(nh));            // opaque per block: ONE base register + immediate offsets (hoisted out of the
-                                              // block loop, the 32 precomputed addresses were spilled and reloaded per step)
-      auto cn_of = [&](int g, int part) {
-        return *reinterpret_cast<const float4*>(lds_n + nh + (32 * (g * G2 + (part >> 2)) + 8 * (part & 3)));
-      };
       auto fetch = [&](int buf, int step) {
         const int g = step / STEPS, t = step % STEPS;
 #pragma unroll
@@ -358,19 +361,32 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
           fl[buf][tile] = *reinterpret_cast<const f16x8_t*>(lds_l + (32 * (g * G2 + tile) + j) * stride + 16 * t + 8 * h);
         }
       };
-      // selection over the 4 clusters (tile, q) of group g this lane holds in acc[ab][tile][4 q ..]: 20 VALU instructions
-      auto select4 = [&](int ab, int g, int part, const float4 cn) {
+      // The scan works on the MFMA's own output s = 2^(shifts) (x.c - |c|^2/2): -|c|^2/2 enters as one more k-step (three exact
+      // fp16 pieces of the table side times the row's power of two, added LAST so that the products accumulate as before), and
+      // the LARGEST s is the nearest centre.  No fp32 add / mul / fma is left in the scan: compare, v_med3 and selects issue
+      // next to the matrix pipe, fp32 arithmetic does not (profiles/r02_coissue.txt).
+      // selection over the 4 clusters (tile, q) of group g this lane holds in acc[ab][tile][4 q ..]: 16 VALU instructions
+      auto select4 = [&](int ab, int g, int part) {
         const int tile = part >> 2, q = part & 3;
         const int r0 = 32 * (g * G2 + tile) + 8 * q;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = fmaf(m2s, acc[ab][tile][4 * q + e], e == 0 ? cn.x : (e == 1 ? cn.y : (e == 2 ? cn.z : cn.w)));
-          const bool lt = v < best;          // ascending cluster order, strict '<': the first minimum stays
+          const float v = acc[ab][tile][4 * q + e];
+          const bool gt = v > best;          // ascending cluster order, strict '>': the first maximum stays
           second = __builtin_amdgcn_fmed3f(best, second, v);
-          best = lt ? v : best;
-          bidx = lt ? (r0 + e) : bidx;       // the lane's 4 h is added after the loop
+          best = gt ? v : best;
+          bidx = gt ? (r0 + e) : bidx;       // the lane's 4 h is added after the loop
         }
       };
+      f16x8_t cnb;                            // B fragment of the -|c|^2/2 step: the row's 2^(x_shift + e1) in k-slots 0..2 of half-wave 0
+      {
+        const _Float16 pw = (h == 0 && finite) ? (_Float16)ldexpf(1.f, x_shift + a.cn_e1) : (_Float16)0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cnb[q] = (_Float16)0.f;
+        cnb[0] = pw; cnb[1] = pw; cnb[2] = pw;
+      }
+      best = -INFINITY;
+      second = -INFINITY;
       static_assert(G2 * 4 <= STEPS, "one selection part per k-step");
       fetch(0, 0);
 #pragma unroll
@@ -396,16 +412,26 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
 #pragma unroll
           for (int tile = 0; tile < G2; ++tile)
             acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[buf][tile], xh[t], acc[ab][tile], 0, 0, 0);
-          if (g > 0 && t < G2 * 4) select4(ab ^ 1, g - 1, t, cnb);   // the previous group's selection, a part under each step's MFMAs
-          {
-            const int g1 = (step + 1) / STEPS, t1 = (step + 1) % STEPS;
-            if (step + 1 < NG * STEPS && g1 > 0 && t1 < G2 * 4) cnb = cn_of(g1 - 1, t1);
+          if (t == STEPS - 1) {                  // - |c|^2 / 2 . 2^(shifts), after every product of the group
+#pragma unroll
+            for (int tile = 0; tile < G2; ++tile) {
+              const f16x4_t pk = *reinterpret_cast<const f16x4_t*>(lds_k + 4 * (32 * (g * G2 + tile) + j));
+              f16x8_t ca;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) ca[q] = (_Float16)0.f;
+              if (h == 0) { ca[0] = pk[0]; ca[1] = pk[1]; ca[2] = pk[2]; }
+              acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, cnb, acc[ab][tile], 0, 0, 0);
+            }
           }
+          if (g > 0 && t < G2 * 4) select4(ab ^ 1, g - 1, t);   // the previous group's selection, a part under each step's MFMAs
           __builtin_amdgcn_sched_barrier(0);     // keep the steps apart: hoisting every fetch to the top spills
         }
       }
 #pragma unroll
-      for (int part = 0; part < G2 * 4; ++part) select4((NG - 1) & 1, NG - 1, part, cn_of(NG - 1, part));
+      for (int part = 0; part < G2 * 4; ++part) select4((NG - 1) & 1, NG - 1, part);
+      // back to v = |c|^2 - 2 x.c = m2s s (exact: a power of two), where the smallest is the nearest
+      best *= m2s;
+      second *= m2s;
     } else {
 #pragma unroll
     for (int g0 = 0; g0 < NT; g0 += G) {
@@ -461,7 +487,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
     const float eps = 2.f * (4.8e-7f + 2.4e-7f + 4.8e-5f + 7.7e-6f + 1e-9f) * xc * (1.f + sqrt_d * 1e-9f) + 2.4e-7f * (a.cmax * a.cmax + 2.f * xc);
     const int within = second <= best + 2.f * eps ? 2 : 1;
     // settled: exactly one cluster within the margin (the minimum itself) and everything finite
-    const bool settled = within == 1 && finite && fabsf(best) <= 3.0e38f;
+    const bool settled = within == 1 && finite && fabsf(best) <= 3.0e38f && bidx < a.K;   // (a padded cluster never settles a row)
     // the rest goes on this workgroup's list: one LDS atomic per wave (ballot + prefix count)
     const bool amb = h == 0 && rvalid && !settled;
     const unsigned long long amask = __ballot(amb);
@@ -563,8 +589,8 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(ws);
     int64_t* rows = reinterpret_cast<int64_t*>(ws + cnt_b);
     Assign16Args p{d_desc, total, cb->D, ld, static_cast<const _Float16*>(cb->d_c16), cb->d_cnorm, cb->K_pad, cb->D_pad16,
-                   cb->c16_shift, cb->cmax, d_labels, rows, cnt, cap};
-    const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4;
+                   cb->c16_shift, cb->cmax, static_cast<const _Float16*>(cb->d_cnk), cb->cn_e1, cb->K, d_labels, rows, cnt, cap};
+    const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4 + (size_t)cb->K_pad * 8;
     PVS_TRY(launch_assign16(ctx, p, kind, cb->K_pad / 32, vec, lds16, grid));
     a.rows = rows;
     a.nrows = cnt;
