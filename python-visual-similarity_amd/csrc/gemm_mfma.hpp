@@ -67,6 +67,7 @@ struct GemmArgs {
   int accumulate;         // != 0: out += result (a long row dimension processed in segments, one launch each)
 };
 
+constexpr bool F16_PRIO = true;      // s_setprio 1 around the fp16 MFMA block (measured: profiles/r02_fp16sim_*)
 constexpr int GEMM_ROW_BYTES = 128;  // bytes of one operand row in a k-tile
 constexpr int GEMM_KBLOCK = 1024;    // k-values per MFMA accumulation chain (two-level summation)
 enum { GEMM_MODE_FULL = 0, GEMM_MODE_PARTIAL = 1, GEMM_MODE_REDUCE = 2 };
@@ -344,12 +345,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (F16) {
           // one 16-B fragment = 8 halfs = this lane's k-slice of a 32x32x16 MFMA (k = 16*t + 8*h + j)
+          if constexpr (F16_PRIO) __builtin_amdgcn_s_setprio(1);   // the MFMA block outranks the SIMD partner's read / DMA issue
 #pragma unroll
           for (int a = 0; a < MI; ++a)
 #pragma unroll
             for (int b = 0; b < NI; ++b)
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, av[c][a]),
                                                                  __builtin_bit_cast(f16x8_t, bv[c][b]), acc[a][b], 0, 0, 0);
+          if constexpr (F16_PRIO) __builtin_amdgcn_s_setprio(0);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

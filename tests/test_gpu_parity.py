@@ -439,7 +439,7 @@ def test_symmetric_pair_scheme_on_one_gpu(gpu_ctx, world, n_total):
     ops = pd.DeviceOps(gpu_ctx)
 
     def new_tensor(shape, dtype, fill):
-        t_ = torch.full(shape, fill, dtype=dtype, device=dev)
+        t_ = torch.full(shape, fill, dtype=getattr(torch, dtype), device=dev)
         torch.cuda.synchronize()
         return t_
 
@@ -455,6 +455,26 @@ def test_symmetric_pair_scheme_on_one_gpu(gpu_ctx, world, n_total):
         got_i.append(i_.cpu().numpy()); got_v.append(v_.cpu().numpy())
     assert np.array_equal(np.concatenate(got_i), ref_idx)
     assert np.array_equal(np.concatenate(got_v), ref_val)
+
+    # the same scheme without torch: pvs_malloc memory behind DevArray views, pool-allocated lists (pvsim.distributed)
+    if world <= 3:
+        pool = pd.DevicePool(gpu_ctx)
+        d_enc = pool.empty((world * B, L), "float32").upload(enc_all.cpu().numpy())
+        d_inv = pool.empty((world * B,), "float32").upload(inv_all.cpu().numpy())
+        ops_s = pd.DeviceOps(gpu_ctx, same_stream=True)
+        st2 = [pd.symmetric_local(d_enc, d_inv, n_total, r, world, k, ops_s, pool.full) for r in range(world)]
+        gpu_ctx.sync()
+        for r in range(world):
+            for p_ in range(world):
+                st2[r]["m_idx"][p_].upload(st2[p_]["s_idx"][r].numpy())
+                st2[r]["m_val"][p_].upload(st2[p_]["s_val"][r].numpy())
+        gi, gv = [], []
+        for r in range(world):
+            i_, v_ = pd.symmetric_finish(st2[r], ops_s, pool.full)
+            gpu_ctx.sync()
+            gi.append(i_.numpy()); gv.append(v_.numpy())
+        assert np.array_equal(np.concatenate(gi), ref_idx) and np.array_equal(np.concatenate(gv), ref_val)
+        pool.close()
 
 
 # ======================================================================================= deep features (config 3 front end)

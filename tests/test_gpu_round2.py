@@ -309,3 +309,25 @@ def test_deep_features_reach_the_encoder_without_a_host_round_trip():
     v_dev = venc.encode(imgs)
     v_host = venc.encode_descriptors([feats[i] for i in range(len(imgs))])
     assert np.array_equal(v_dev, v_host)
+
+
+def test_sharded_index_without_torch(gpu_ctx, tables):
+    """pvsim.distributed.ShardedVLADIndex on one GPU with no torch object anywhere: pvs_malloc memory (DevArray / DevicePool),
+    descriptors uploaded through the C-ABI, encode -> (no exchange at world 1) -> all-vs-all top-k; equal to the host entry points."""
+    from pvsim import distributed as pd
+    rng = np.random.default_rng(12)
+    imgs = [synth.sift_like(int(n), rng).astype(np.uint8) for n in rng.integers(40, 400, size=37)]
+    packed, off = pack_descriptors(imgs, 128, np.uint8)
+    cb = gpu_ctx.codebook(tables["centroids"])
+    pool = pd.DevicePool(gpu_ctx)
+    d_x = pool.empty(packed.shape, "uint8").upload(packed)
+    d_off = pool.empty(off.shape, "int64").upload(off)
+    index = pd.ShardedVLADIndex(gpu_ctx, cb, len(imgs))
+    index.encode_local(d_x.ptr, DESC_U8_ROOTSIFT, d_off.ptr, int(off[-1]))
+    index.exchange()
+    idx, val = index.topk(4)
+    enc = gpu_ctx.vlad_encode(cb, packed, off, DESC_U8_ROOTSIFT)
+    ridx, rval = gpu_ctx.cosine_topk(enc, enc, 4)
+    assert np.array_equal(index.enc_loc.numpy()[: len(imgs)], enc)
+    assert np.array_equal(idx, ridx) and np.array_equal(val.view(np.uint32), rval.view(np.uint32))
+    pool.close()
