@@ -11,6 +11,7 @@
 #include <vector>
 #include <cstring>
 
+#define PVS_GEMM_DBG 1
 #include "../gemm_mfma.hpp"
 
 using namespace pvs;
@@ -64,6 +65,7 @@ __global__ void ref_samples_h(const _Float16* x, const float* inv, int64_t L, in
 
 __device__ __attribute__((aligned(16))) float d_zero16[4] = {0, 0, 0, 0};
 static int64_t g_ld = 0;  // operand row stride (floats)
+static int g_dbg = 0;     // ablation bits for stamped builds
 
 static std::vector<GemmTile> tile_list(int tm_n, int tn_n, bool symm) {
   std::vector<GemmTile> t;
@@ -85,13 +87,14 @@ static std::vector<GemmTile> tile_list(int tm_n, int tn_n, bool symm) {
 
 // TAILK > 1: the tiles of the last partial round (slots = 512) go through the split-K tail
 template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, bool STAMP = false, bool F16 = false,
-          bool TWO = true, bool ILV = false, int LW = WM * WN>
+          bool TWO = true, bool ILV = false, int LW = WM * WN, bool PP = false>
 static void run(const char* name, const void* A, const float* inv, int64_t N, int64_t L, float* out, int ns,
                 const double* ref_h, const int* sm_h, const int* sn_h, int tailk) {
   using Cfg = GemmCfg<BM, BN, WM, WN, STAGES, F16, LW>;
+  constexpr int LDSB = PP ? RING_LDS_BYTES : Cfg::LDS_BYTES;
   GemmArgs g{};
   g.A = A; g.B = A; g.M = N; g.N = N; g.L = L; g.lda = g_ld; g.ldb = g_ld; g.inva = inv; g.invb = inv; g.out = out;
-  g.ldo = N; g.splitk = 1;
+  g.ldo = N; g.splitk = 1; g.dbg = g_dbg;
   CK(hipGetSymbolAddress((void**)&g.zero16, HIP_SYMBOL(d_zero16)));
   std::vector<GemmTile> t = tile_list((int)((N + BM - 1) / BM), (int)((N + BN - 1) / BN), SYMM);
   GemmTile* d_t; CK(hipMalloc(&d_t, t.size() * sizeof(GemmTile)));
@@ -102,20 +105,20 @@ static void run(const char* name, const void* A, const float* inv, int64_t N, in
   if (tailk > 1 && total > slots && total % slots) { n_tail = total % slots; n_main = total - n_tail; }
   float* part = nullptr;
   if (n_tail) CK(hipMalloc(&part, (size_t)n_tail * (TWO ? (size_t)((L + 1023) / 1024) : (size_t)tailk) * BM * BN * 4));
-  auto kf = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_FULL, STAMP, F16, TWO, ILV, false, LW>;
-  auto kp = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_PARTIAL, false, F16, TWO, ILV, false, LW>;
-  auto kr = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_REDUCE, false, F16, TWO, ILV, false, LW>;
+  auto kf = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_FULL, STAMP, F16, TWO, ILV, false, LW, PP>;
+  auto kp = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_PARTIAL, false, F16, TWO, ILV, false, LW, PP>;
+  auto kr = gemm_mfma_kernel<BM, BN, WM, WN, STAGES, SYMM, OCC, GEMM_MODE_REDUCE, false, F16, TWO, ILV, false, LW, PP>;
   for (const void* k : {(const void*)kf, (const void*)kp, (const void*)kr})
-    CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
   if (STAMP) CK(hipMalloc(&g.stamps, (size_t)n_main * 64));
   auto launch = [&]() {
     GemmArgs a = g;
     a.tile_base = 0;
-    hipLaunchKernelGGL(kf, dim3((unsigned)n_main), dim3(Cfg::THREADS), Cfg::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL(kf, dim3((unsigned)n_main), dim3(Cfg::THREADS), LDSB, 0, a);
     if (n_tail) {
       a.tile_base = n_main; a.splitk = tailk; a.nparts = TWO ? (int)((L + 1023) / 1024) : tailk; a.partial = part;
-      hipLaunchKernelGGL(kp, dim3((unsigned)(n_tail * tailk)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, 0, a);
-      hipLaunchKernelGGL(kr, dim3((unsigned)n_tail), dim3(Cfg::THREADS), Cfg::LDS_BYTES, 0, a);
+      hipLaunchKernelGGL(kp, dim3((unsigned)(n_tail * tailk)), dim3(Cfg::THREADS), LDSB, 0, a);
+      hipLaunchKernelGGL(kr, dim3((unsigned)n_tail), dim3(Cfg::THREADS), LDSB, 0, a);
     }
   };
   CK(hipMemset(out, 0xff, (size_t)N * N * 4));
@@ -155,8 +158,8 @@ static void run(const char* name, const void* A, const float* inv, int64_t N, in
     }
     std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
     const double nkt = (double)n_main * (double)((L + Cfg::BK - 1) / Cfg::BK);
-    printf("   [stamped build] clock %.3f GHz; block loop %.1f cyc per k-tile; per k-tile: vmcnt %.0f barrier %.0f"
-           " issue %.0f reads+MFMA %.0f\n", clk[clk.size() / 2], cyc[cyc.size() / 2] / (double)((L + Cfg::BK - 1) / Cfg::BK), seg[0] / nkt,
+    printf("   [stamped build] clock %.3f GHz; block loop %.1f cyc per k-tile; per k-tile: seg0 %.0f seg1 %.0f"
+           " seg2 %.0f seg3 %.0f  (k-loop: vmcnt / barrier / issue / reads+MFMA;  ping-pong: reads / barrier / lgkm+MFMA / barrier)\n", clk[clk.size() / 2], cyc[cyc.size() / 2] / (double)((L + Cfg::BK - 1) / Cfg::BK), seg[0] / nkt,
            seg[1] / nkt, seg[2] / nkt, seg[3] / nkt);
     CK(hipFree(g.stamps));
   }
@@ -238,6 +241,24 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(ref_samples_h, dim3(ns), dim3(64), 0, 0, A16, inv, L, g_ld, d_sm, d_sn, ns, d_ref);
     std::vector<double> refh(ns);
     CK(hipMemcpy(refh.data(), d_ref, ns * 8, hipMemcpyDeviceToHost));
+    if (which == 2 && argc > 5) {   // ping-pong A/B, interleaved rounds in one process
+      for (int round = 0; round < atoi(argv[5]); ++round) {
+        RUNH(256, 256, 2, 4, 2, false, 2, true, 1);
+        run<256, 256, 2, 4, 2, false, 2, false, true, false, false, 8, true>("f16 256x256 ping-pong", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
+        run<256, 256, 2, 4, 2, true, 2, false, true, false, false, 8, true>("f16 256x256 ping-pong symm", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 8);
+        RUNH(256, 256, 2, 4, 2, true, 2, true, 8);
+      }
+      for (int d : {0, 2, 6}) {
+        g_dbg = d;
+        char nm[64]; snprintf(nm, sizeof nm, "f16 ping-pong dbg%d", d);
+        run<256, 256, 2, 4, 2, false, 2, false, true, false, false, 8, true>(nm, A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
+        snprintf(nm, sizeof nm, "f16 ping-pong stamped dbg%d", d);
+        run<256, 256, 2, 4, 2, false, 2, true, true, false, false, 8, true>(nm, A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
+      }
+      g_dbg = 0;
+      run<256, 256, 2, 4, 2, false, 2, true, true, false, true, 8, false>("f16 256x256 ilv stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
+      return 0;
+    }
     RUNH(256, 256, 2, 4, 2, false, 2, false, 1);
     run<256, 256, 2, 4, 2, false, 2, false, true, false, false, 4>("f16 256x256 LW4", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
     run<256, 256, 2, 4, 2, false, 2, true, true, false, false, 4>("f16 256x256 LW4 stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);

@@ -65,8 +65,12 @@ struct GemmArgs {
   const float* zero16;    // 16 B of zeros in device memory (source for k-chunks past L)
   unsigned long long* stamps;  // diagnostic builds only (STAMP)
   int accumulate;         // != 0: out += result (a long row dimension processed in segments, one launch each)
+  int dbg;                // STAMP builds only (ablation): 1 no LDS-DMA in the k-loop, 2 no fragment reads after the first tile, 4 no MFMA, 8 all tiles load panel 0
 };
 
+#ifndef PVS_GEMM_DBG
+#define PVS_GEMM_DBG 0   // 1 (variant harness only): GemmArgs::dbg ablation bits are honoured by unstamped builds too
+#endif
 constexpr bool F16_PRIO = true;      // s_setprio 1 around the fp16 MFMA block (measured: profiles/r02_fp16sim_*)
 constexpr int GEMM_ROW_BYTES = 128;  // bytes of one operand row in a k-tile
 constexpr int GEMM_KBLOCK = 1024;    // k-values per MFMA accumulation chain (two-level summation)
@@ -201,13 +205,84 @@ struct GemmLoader {
   }
 };
 
+// ---- ping-pong kernel: operand ring.  A k-tile is four UNITS of 128 rows x 128 B (A top, A bottom, B left, B right; same
+// swizzled image as above, row-local); the whole LDS is a ring of 10 unit slots (160 KB).  Unit j = 4 * tile + type sits in
+// slot j % 10.  Every wave loads rows [16 w, 16 w + 16) of every unit (two LDS-DMA instructions, 1 KB each) and reads
+// fragments from exactly one A unit (its wave row) and one B unit (its wave-column pair).
+constexpr int RING_UNITS = 10, RING_UNIT_BYTES = 128 * GEMM_ROW_BYTES, RING_LDS_BYTES = RING_UNITS * RING_UNIT_BYTES;
+
+struct GemmRingLoader {
+  const char* base_a;   // operand at the tile's first row, minus 1 KiB (the second load of a pair carries offset:1024)
+  const char* base_b;
+  unsigned voff[4][2];  // [unit type][q]: per-lane byte offset from base (row * ld * 2 + swizzled chunk * 16 + 1 KiB - q KiB)
+  unsigned gce[2];      // [q]: first element of this lane's 16-B chunk inside the k-tile (k-tail check)
+  int wave_off;         // 2 KiB * wave: this wave's rows inside a unit
+
+  __device__ __forceinline__ void init(const GemmArgs& g, int64_t m0, int64_t n0, int wave, int lane) {
+    wave_off = wave * 2048;
+    base_a = static_cast<const char*>(g.A) + m0 * g.lda * 2 - 1024;
+    base_b = static_cast<const char*>(g.B) + n0 * g.ldb * 2 - 1024;
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int r = 16 * wave + 8 * q + (lane >> 3);            // row inside the unit
+        const int gc = (lane & 7) ^ ((r >> 1) & 7);
+        const bool is_a = ut < 2;
+        const int64_t row0 = is_a ? m0 : n0, nrows = is_a ? g.M : g.N, ld = is_a ? g.lda : g.ldb;
+        int64_t grow = row0 + 128 * (ut & 1) + r;
+        grow = grow < nrows ? grow : nrows - 1;                   // rows past the edge are computed and discarded
+        voff[ut][q] = (unsigned)((grow - row0) * ld * 2 + 16 * gc + 1024 - q * 1024);
+        gce[q] = 8 * gc;                                          // (the chunk column depends on q only)
+      }
+  }
+  // the two units of one operand (A: types 0, 1; B: types 2, 3) of k-tile kt into slots s0, s1: 4 instructions
+  template <bool IS_A>
+  __device__ __forceinline__ void issue(int64_t k0, unsigned lds0, int s0, int s1) const {
+    const char* sb = (IS_A ? base_a : base_b) + k0 * 2;
+    const unsigned m0a = lds0 + s0 * RING_UNIT_BYTES + wave_off, m0b = lds0 + s1 * RING_UNIT_BYTES + wave_off;
+    constexpr int U = IS_A ? 0 : 2;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %2\n\t"
+                 "global_load_lds_dwordx4 %4, %2 offset:1024\n\t"
+                 "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %5, %2\n\t"
+                 "global_load_lds_dwordx4 %6, %2 offset:1024"
+                 ::"s"(m0a), "s"(m0b), "s"(sb), "v"(voff[U][0]), "v"(voff[U][1]), "v"(voff[U + 1][0]), "v"(voff[U + 1][1])
+                 : "memory");
+  }
+  // last k-tile when L % 64 != 0: chunks at or past L come from a zero buffer (builtin path, rare)
+  template <bool IS_A>
+  __device__ __forceinline__ void issue_checked(const GemmArgs& g, int64_t k0, char* smem, int s0, int s1) const {
+    constexpr int U = IS_A ? 0 : 2;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const char* p = (k0 + gce[q] < g.L) ? (IS_A ? base_a : base_b) + k0 * 2 + (size_t)voff[U + u][q] + q * 1024
+                                         : reinterpret_cast<const char*>(g.zero16);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)(smem + (u ? s1 : s0) * RING_UNIT_BYTES + wave_off + q * 1024),
+                                         16, 0, 0);
+      }
+  }
+};
+
+template <int IMM>
+__device__ __forceinline__ void ds_read_frag_imm(f32x4_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
+}
+
 // OCC = minimum waves per SIMD the register allocator must leave room for (blocks per CU * threads / 256)
 // TWO = two-level accumulation (needed for fp32-grade sums; off for the fp16 path, whose input rounding dominates)
 // ILV = spread the next tile's LDS-DMA issue over the four k-steps of the current tile instead of one burst
 // DUAL = besides out[m][n] also write the transposed panel out_t[n][m] (every tile), so that one GEMM serves the
 //        row queries AND the column queries of a block pair (multi-GPU symmetric scheme).
+// PP = ping-pong schedule (fp16, two wave groups = the two rows of waves, one wave of each group per SIMD): a k-tile is two
+//      phases of [12 fragment reads | barrier | 16 MFMAs | barrier]; the second group runs one barrier behind the first, so
+//      on every SIMD one wave feeds the matrix pipe while the other reads its next fragments and issues the LDS-DMA.
 template <int BM, int BN, int WM, int WN, int STAGES, bool SYMM, int OCC, int MODE = GEMM_MODE_FULL, bool STAMP = false,
-          bool F16 = false, bool TWO = true, bool ILV = false, bool DUAL = false, int LW = WM * WN>
+          bool F16 = false, bool TWO = true, bool ILV = false, bool DUAL = false, int LW = WM * WN, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g) {
   using Cfg = GemmCfg<BM, BN, WM, WN, STAGES, F16, LW>;
   constexpr int GEMM_BK = Cfg::BK;
@@ -274,16 +349,18 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
     const bool ktail = (g.L % GEMM_BK) != 0;  // only the last k-tile can reach past L
     GemmLoader<Cfg> ld;
     const bool loader = wave < Cfg::LOADER_WAVES;  // wave-uniform
-    if (loader) ld.init(g, m0, n0, wave, lane);
+    if (loader && !PP) ld.init(g, m0, n0, wave, lane);
     auto stage_tile = [&](int t) {
       if (!loader) return;
       char* st = smem + ((t - kt0) % STAGES) * Cfg::STAGE_BYTES;
       if (ktail && t == nk_all - 1) ld.issue_checked(g, (int64_t)t * GEMM_BK, st);
       else ld.template issue<0, Cfg::LOADS_PER_WAVE>((int64_t)t * GEMM_BK, st);
     };
+    if constexpr (!PP) {
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-      if (kt0 + s < kt1) stage_tile(kt0 + s);
+      for (int s = 0; s < STAGES - 1; ++s)
+        if (kt0 + s < kt1) stage_tile(kt0 + s);
+    }
 
     // per-lane fragment offsets inside a stage for the four k-steps (swizzled chunk cc = 2t + h)
     unsigned offa[MI][4], offb[NI][4];
@@ -301,6 +378,120 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_mfma_kernel(GemmArgs g
       st_r0 = __builtin_amdgcn_s_memrealtime();
     }
 
+    if constexpr (PP) {
+      static_assert(F16 && !TWO && !ILV && STAGES == 2 && WM == 2 && WN == 4 && BM == 256 && BN == 256 && LW == 8,
+                    "ping-pong: fp16, 256 x 256, eight waves");
+      // Two wave groups (the two rows of waves; one wave of each group per SIMD).  A k-tile is two phases of
+      // [12 fragment reads | barrier | 16 MFMAs | barrier]; group 1 runs one barrier behind group 0, so on every SIMD one wave
+      // feeds the matrix pipe while the other reads its next fragments.  Barrier intervals of tile u (b = 4 u):
+      //                group 0                                          group 1
+      //   [b,   b+1)   LDS-DMA B(u+1); MFMA phase 0                     LDS-DMA B(u+1); reads phase 0
+      //   [b+1, b+2)   reads phase 1                                    MFMA phase 0
+      //   [b+2, b+3)   LDS-DMA A(u+2); MFMA phase 1, then vmcnt         LDS-DMA A(u+2); reads phase 1, then vmcnt
+      //   [b+3, b+4)   reads phase 0 of tile u+1                        MFMA phase 1
+      // The ring keeps 96 KB in flight: B(u+1) has one tile period to land, A(u+2) two (the L2 -> LDS path of a CU moves
+      // ~70 GB/s: 64 KB per k-tile take 0.9 us of the ~1.1 us a k-tile's MFMAs take -- one burst per tile, waited for at the
+      // end of the tile, was the bound of the two-stage kernel).  vmcnt(4) leaves exactly the four A(u+2) loads outstanding.
+      // RAW: every issuer's vmcnt precedes barrier b+3, the first read of tile u+1 follows it.  WAR: slots of tile u-1 are
+      // refilled after barrier b; its last reads (group 1, [b-2, b-1)) were retired (lgkmcnt(0)) before barrier b.
+      const bool g1 = wm != 0;
+      constexpr bool DBG = STAMP || PVS_GEMM_DBG;
+      const int dbg = DBG ? g.dbg : 0;
+      GemmRingLoader rl;
+      rl.init(g, (dbg & 8) ? 0 : m0, (dbg & 8) ? 0 : n0, wave, lane);     // dbg 8: every tile streams the same two panels
+      const int T = kt1 - kt0;
+      auto load = [&](int u, bool is_a) {     // units of local tile u: A -> slots (4u, 4u+1) % 10, B -> (4u+2, 4u+3) % 10
+        const int kt = kt0 + u;
+        const int j = 4 * u + (is_a ? 0 : 2);
+        const int s0 = j % RING_UNITS, s1 = (j + 1) % RING_UNITS;
+        const int64_t k0 = (int64_t)kt * GEMM_BK;
+        if (ktail && kt == nk_all - 1) {
+          if (is_a) rl.issue_checked<true>(g, k0, smem, s0, s1);
+          else rl.issue_checked<false>(g, k0, smem, s0, s1);
+        } else {
+          if (is_a) rl.issue<true>(k0, lds0, s0, s1);
+          else rl.issue<false>(k0, lds0, s0, s1);
+        }
+      };
+      // per-lane fragment offset inside a unit for the four k-steps; fragment m of a k-step is + 4096 m (immediate)
+      unsigned fo[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fo[t] = 128 * i + 16 * ((2 * t + h) ^ ((i >> 1) & 7));
+      const unsigned b_half = (wn & 1) * 8192;     // this wave's 64 rows inside its B unit
+      if (T > 0) { load(0, true); load(0, false); }
+      if (T > 1) { load(1, true); wait_vm<4>(); } else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      if (g1) __builtin_amdgcn_s_barrier();
+      f32x4_t av[2][MI], bv[2][NI];
+      for (int u = 0; u < T; ++u) {
+        const unsigned base_a = lds0 + ((4 * u + wm) % RING_UNITS) * RING_UNIT_BYTES;
+        const unsigned base_b = lds0 + ((4 * u + 2 + (wn >> 1)) % RING_UNITS) * RING_UNIT_BYTES + b_half;
+        const bool more1 = u + 1 < T && !(dbg & 1), more2 = u + 2 < T && !(dbg & 1);
+        auto issue_b = [&]() { if (more1) load(u + 1, false); };
+        auto issue_a = [&]() { if (more2) load(u + 2, true); };
+        auto landed = [&]() {
+          if (more2) wait_vm<4>();
+          else wait_vm<0>();
+        };
+        auto reads = [&](int p) {
+          if (DBG && (dbg & 2) && u != 0) return;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned aa = base_a + fo[2 * p + s2], ab = base_b + fo[2 * p + s2];
+            ds_read_frag_imm<0>(av[s2][0], aa);
+            ds_read_frag_imm<4096>(av[s2][1], aa);
+            ds_read_frag_imm<8192>(av[s2][2], aa);
+            ds_read_frag_imm<12288>(av[s2][3], aa);
+            ds_read_frag_imm<0>(bv[s2][0], ab);
+            ds_read_frag_imm<4096>(bv[s2][1], ab);
+          }
+        };
+        auto mfmas = [&]() {
+          wait_lgkm<0>();
+          __builtin_amdgcn_sched_barrier(0);
+          if (DBG && (dbg & 4)) return;
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+              for (int b = 0; b < NI; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, av[s2][a]),
+                                                                   __builtin_bit_cast(f16x8_t, bv[s2][b]), acc[a][b], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0, p8 = 0;
+        if constexpr (STAMP) p0 = __builtin_amdgcn_s_memtime();
+        if (g1) issue_b();
+        reads(0);
+        if constexpr (STAMP) p1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) p2 = __builtin_amdgcn_s_memtime();
+        if (!g1) issue_b();
+        mfmas();
+        if constexpr (STAMP) p3 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) p4 = __builtin_amdgcn_s_memtime();
+        if (g1) issue_a();
+        reads(1);
+        if (g1) landed();
+        if constexpr (STAMP) p5 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) p6 = __builtin_amdgcn_s_memtime();
+        if (!g1) issue_a();
+        mfmas();
+        if (!g1) landed();
+        if constexpr (STAMP) p7 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) {   // [0] read issue, [1] barrier after the reads, [2] lgkmcnt + 16 MFMAs (+ vmcnt), [3] barrier after the MFMAs
+          p8 = __builtin_amdgcn_s_memtime();
+          seg[0] += (p1 - p0) + (p5 - p4); seg[1] += (p2 - p1) + (p6 - p5); seg[2] += (p3 - p2) + (p7 - p6); seg[3] += (p4 - p3) + (p8 - p7);
+        }
+      }
+      if (!g1) __builtin_amdgcn_s_barrier();
+    } else
     for (int kt = kt0; kt < kt1; ++kt) {
       unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
       if constexpr (STAMP) s0 = __builtin_amdgcn_s_memtime();

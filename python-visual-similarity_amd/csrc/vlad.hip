@@ -294,30 +294,40 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
       }
     }
     }
-    if constexpr (DescTraits<KIND>::rootsift) {
-      float s = 0.f;
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += xf[t][q];
-      s += __shfl_xor(s, 32, 64);   // integer-valued rows: the sum is exact, any order
-      const RootsiftRow<KIND> rr(s);
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) xf[t][q] = rr(xf[t][q]);
-    }
     // ---- row norm, row scale (largest |x| 2^shift in [2^12, 2^13)), hi / lo halves
-    float n2 = 0.f, amax = 0.f;
+    float n2 = 0.f, amax = 0.f, rs_r = 0.f;
+    if constexpr (DescTraits<KIND>::rootsift) {
+      // The prefilter does not need the reference's bits of sqrt(raw / (sum + 1e-7)), only a value within a known distance of
+      // them: y' = v_sqrt(raw * (1 / d)) is within 2^-21 relative of the exact element (1/d, the product and the square root
+      // round once each: 2^-24 + 2^-24 halved by the root, + 1 ulp of v_sqrt_f32; a raw row sum formed in another order than the
+      // exact kernel's moves every element by the same few ulps), which adds 2^-21 |x||c| to a product -- 1 % of the margin
+      // (`eps` below carries it).  |x|^2 = sum / d and the largest element follow from the raw row: 3 instead of 16 vector
+      // instructions per element, none of them in the exact kernels (assign_kernel, aggregate, fused), whose values are unchanged.
+      float s = 0.f, rmax = 0.f;
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+      for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        n2 = fmaf(xf[t][q], xf[t][q], n2);
-        amax = fmaxf(amax, fabsf(xf[t][q]));
-      }
-    n2 += __shfl_xor(n2, 32, 64);
-    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        for (int q = 0; q < 8; ++q) {
+          s += xf[t][q];
+          rmax = fmaxf(rmax, xf[t][q]);
+        }
+      s += __shfl_xor(s, 32, 64);
+      rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+      rs_r = 1.0f / (s + 1e-7f);
+      n2 = s * rs_r * 1.0001f;                                   // >= |x|^2 of the exact row (every element within 2^-21)
+      amax = __builtin_amdgcn_sqrtf(rmax * rs_r) * 1.0001f;      // >= the largest element
+      if (!(s >= 0.f) || !(rmax * rs_r <= 3.0e38f)) n2 = NAN;    // negative / non-finite raw rows go to the exact kernel
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          n2 = fmaf(xf[t][q], xf[t][q], n2);
+          amax = fmaxf(amax, fabsf(xf[t][q]));
+        }
+      n2 += __shfl_xor(n2, 32, 64);
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    }
     const float nx = sqrtf(n2) * 1.0001f;
     int ex = 13;
     if (amax > 0.f) (void)frexpf(amax, &ex);
@@ -328,12 +338,15 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
       if (x_shift + a.cn_e1 < -14 || x_shift + a.cn_e1 > 15) finite = false;
     }
     const float xs = ldexpf(1.f, x_shift);
+    const float rs_rs = rs_r * xs * xs;     // rootsift kinds: sqrt(raw r) 2^shift = sqrt(raw r 4^shift), the scale is exact
     f16x8_t xh[8], xl[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float v = xf[t][q] * xs;
+        float v;
+        if constexpr (DescTraits<KIND>::rootsift) v = __builtin_amdgcn_sqrtf(xf[t][q] * rs_rs);
+        else v = xf[t][q] * xs;
         const _Float16 hi = (_Float16)v;
         xh[t][q] = hi;
         xl[t][q] = (_Float16)(v - (float)hi);
@@ -484,7 +497,8 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
       if (take) bidx = oi;
     }
     const float xc = nx * a.cmax;
-    const float eps = 2.f * (4.8e-7f + 2.4e-7f + 4.8e-5f + 7.7e-6f + 1e-9f) * xc * (1.f + sqrt_d * 1e-9f) + 2.4e-7f * (a.cmax * a.cmax + 2.f * xc);
+    constexpr float conv_err = DescTraits<KIND>::rootsift ? 4.8e-7f : 0.f;   // 2^-21: the approximate RootSIFT elements above
+    const float eps = 2.f * (4.8e-7f + 2.4e-7f + 4.8e-5f + 7.7e-6f + 1e-9f + conv_err) * xc * (1.f + sqrt_d * 1e-9f) + 2.4e-7f * (a.cmax * a.cmax + 2.f * xc);
     const int within = second <= best + 2.f * eps ? 2 : 1;
     // settled: exactly one cluster within the margin (the minimum itself) and everything finite
     const bool settled = within == 1 && finite && fabsf(best) <= 3.0e38f && bidx < a.K;   // (a padded cluster never settles a row)
