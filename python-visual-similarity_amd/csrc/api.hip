@@ -551,8 +551,9 @@ PVS_EXPORT int pvs_vlad_encode_dev(pvs_ctx* ctx, const pvs_codebook* cb, const p
   if (!labels)
     PVS_TRY(ws_reserve(ctx, 1, (size_t)std::max<int64_t>(total_desc, 1) * sizeof(int32_t),
                        reinterpret_cast<void**>(&labels)));
-  PVS_TRY(launch_assign(ctx, cb, x, kind, total_desc, ld, labels));
-  return launch_vlad_aggregate(ctx, cb, x, kind, ld, d_offsets, n_images, labels, *prm, d_out, d_inv_norm);
+  const float2* rowstat = nullptr;   // uint8 rows: per-row (sum + 1e-7, reciprocal) left by the prefilter for the aggregate pass
+  PVS_TRY(launch_assign(ctx, cb, x, kind, total_desc, ld, labels, &rowstat));
+  return launch_vlad_aggregate(ctx, cb, x, kind, ld, d_offsets, n_images, labels, *prm, d_out, d_inv_norm, false, rowstat, total_desc);
 }
 
 static int host_total(const int64_t* offsets, int64_t n_images, int64_t* total) {

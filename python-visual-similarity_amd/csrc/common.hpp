@@ -171,10 +171,11 @@ struct ScopedTimer {
 
 // ---- launchers implemented in the kernel translation units (all enqueue on ctx->stream)
 int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int64_t total, int ld,
-                  int32_t* d_labels);
+                  int32_t* d_labels, const float2** rowstat_out = nullptr);
 int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int ld,
                           const int64_t* d_offsets, int64_t n_images, const int32_t* d_labels,
-                          const pvs_norm_params& prm, float* d_out, float* d_inv_norm, bool raw = false);
+                          const pvs_norm_params& prm, float* d_out, float* d_inv_norm, bool raw = false,
+                          const float2* rowstat = nullptr, int64_t total_hint = 0);
 bool vlad_fused_eligible(const pvs_codebook* cb, const void* d_desc, int kind, int ld, const float* d_out);
 int launch_vlad_fused(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int ld, const int64_t* d_offsets,
                       int64_t n_images, const pvs_norm_params& prm, float* d_out, int32_t* d_labels, float* d_inv_norm, bool raw = false);

@@ -4,6 +4,9 @@
 // For integer-valued SIFT rows (OpenCV's output) every partial sum is an exact integer < 2^24, so the
 // row sum does not depend on the summation order and the fused transform is bit-identical to NumPy.
 #pragma once
+#ifndef PVS_SQRT_RN_MODE
+#define PVS_SQRT_RN_MODE 1
+#endif
 #include "common.hpp"
 
 namespace pvs {
@@ -40,6 +43,8 @@ struct RootsiftRow {
   float d, r;
   __device__ __forceinline__ explicit RootsiftRow(float row_sum)
       : d(row_sum + 1e-7f), r(KIND == PVS_DESC_U8_ROOTSIFT ? 1.0f / (row_sum + 1e-7f) : 0.f) {}
+  // the same two numbers, computed once per row by the assignment pass (uint8 rows: the row sum is an exact integer)
+  __device__ __forceinline__ RootsiftRow(float d_, float r_) : d(d_), r(r_) {}
   __device__ __forceinline__ float operator()(float raw) const {
     if (KIND == PVS_DESC_U8_ROOTSIFT && d <= 32640.5f) {   // the checked domain (D <= 128); longer rows take the IEEE path
       float q = raw * r;
@@ -52,6 +57,44 @@ struct RootsiftRow {
     } else {
       return sqrtf(raw / d);
     }
+  }
+};
+
+// ---- the normalisation epilogue's square root and division, in fewer instructions than the compiler's IEEE sequences and
+// with the same bits (bench/exact_sqrt_div.hip: sqrt_rn == sqrtf on all 2^32 bit patterns; DivByRow == IEEE division on
+// 1.4e11 pairs incl. the edge patterns).  hipcc's sqrtf / division carry denormal scaling and special-case fix-ups (14 and
+// 10 instructions); at K D = 32768 outputs per image these two were a third of the aggregate kernel's instruction stream.
+__device__ __forceinline__ bool sqrt_rn_fast_range(float x) { return x == 0.f || (x >= 0x1p-100f && x <= 0x1p+100f); }
+template <int MODE = PVS_SQRT_RN_MODE>
+__device__ __forceinline__ float sqrt_rn(float x) {
+  if (!sqrt_rn_fast_range(x)) return sqrtf(x);   // denormal, huge, negative, inf, NaN: the IEEE sequence (rare: per-lane branch)
+  const float rs = __builtin_amdgcn_rsqf(fmaxf(x, 0x1p-126f));   // (x = 0: g = 0 * rs = 0, residual 0 -> 0)
+  float g = x * rs, h = 0.5f * rs;
+  if (MODE >= 2) {
+    const float r1 = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r1, g);
+    h = __builtin_fmaf(h, r1, h);
+  }
+  const float e = __builtin_fmaf(-g, g, x);
+  return __builtin_fmaf(e, h, g);
+}
+
+// a / b for many a and one b: r = fl(1 / b) once, then q0 = fl(a r), e = a - q0 b (exact in an fma), q = fl(q0 + e r): the
+// correctly rounded quotient when no intermediate leaves the normal range (Markstein).  `fast` is decided per divisor; the
+// caller guarantees for the dividends of a fast divisor: |a| <= 2^40 |b| ... in short |a / b| in [2^-120, 2^80] or a == +0.
+// (a == -0 would give +0: callers with possibly negative zeros or unbounded dividends use operator() with guard = true.)
+struct DivByRow {
+  float b, r;
+  bool fast;
+  __device__ __forceinline__ explicit DivByRow(float den) : b(den), r(1.0f / den), fast(den >= 0x1p-40f && den <= 0x1p+40f) {}
+  __device__ __forceinline__ float operator()(float a, bool guard = true) const {
+    const float aa = __builtin_fabsf(a);
+    if (fast && (!guard || (aa >= 0x1p-64f && aa <= 0x1p+64f))) {
+      const float q0 = a * r;
+      const float e = __builtin_fmaf(-q0, b, a);
+      return __builtin_fmaf(e, r, q0);
+    }
+    return a / b;
   }
 };
 
@@ -116,6 +159,26 @@ __device__ __forceinline__ float half_max_xor(float v) {
   v = fmaxf(v, lane_xor_f<2>(v));
   v = fmaxf(v, lane_xor_f<1>(v));
   return v;
+}
+
+
+// ---- VLAD normalisation pieces shared by the gather, stream and fused kernels (one definition: the same bits everywhere)
+__device__ __forceinline__ float power_norm(float v, float p) {
+  // np.sign(v) * np.abs(v) ** p  (vlad.py:106); p == 1 and p == 0.5 take exact paths
+  if (p == 1.f) return v;
+  const float a = fabsf(v);
+  if (p == 0.5f) {
+    // v > 0: sqrt, v < 0: -sqrt, v == +-0: +0, NaN: itself (sums only ever hold quiet NaNs, for which v + 0 is v)
+    const float m = sqrt_rn(a);
+    return a > 0.f ? __builtin_copysignf(m, v) : v + 0.f;
+  }
+  const float m = powf(a, p);
+  return v > 0.f ? m : (v < 0.f ? -m : (v == 0.f ? 0.f * m : v));
+}
+
+__device__ __forceinline__ float norm_accum(float v, int mode, float p) {
+  const float a = fabsf(v);
+  return mode == 2 ? v * v : (mode == 1 ? a : (mode == 3 ? a : powf(a, p)));
 }
 
 }  // namespace pvs

@@ -210,6 +210,7 @@ struct Assign16Args {
   int64_t* amb_rows;             // [gridDim][cap]: descriptors left to the exact kernel, one list per workgroup
   unsigned long long* amb_count; // [gridDim]
   int64_t cap;
+  float2* rowstat;               // uint8 rows: (row sum + 1e-7, its reciprocal) per descriptor for the aggregate pass, or null
 };
 
 // STEPS: the number of 16-dim k-steps when it is known at compile time (8 for D_pad16 = 128), 0 = read it from the arguments.
@@ -317,6 +318,9 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
       n2 = s * rs_r * 1.0001f;                                   // >= |x|^2 of the exact row (every element within 2^-21)
       amax = __builtin_amdgcn_sqrtf(rmax * rs_r) * 1.0001f;      // >= the largest element
       if (!(s >= 0.f) || !(rmax * rs_r <= 3.0e38f)) n2 = NAN;    // negative / non-finite raw rows go to the exact kernel
+      if constexpr (KIND == PVS_DESC_U8_ROOTSIFT) {
+        if (a.rowstat != nullptr && h == 0 && rvalid) a.rowstat[row] = make_float2(s + 1e-7f, rs_r);   // = RootsiftRow(s), bit for bit
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -577,7 +581,8 @@ int assign_tiles_for(int K) {
 }
 
 int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int64_t total, int ld,
-                  int32_t* d_labels) {
+                  int32_t* d_labels, const float2** rowstat_out) {
+  if (rowstat_out) *rowstat_out = nullptr;
   if (total <= 0) return PVS_OK;
   const bool rs = kind != PVS_DESC_F32;
   if (rs && cb->D > ASSIGN_DCHUNK)
@@ -599,11 +604,17 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
     const int64_t cap = (nblocks + grid - 1) / grid * ASSIGN_ROWS;   // a workgroup can list at most what it processes
     char* ws = nullptr;
     const size_t cnt_b = ((size_t)grid * 8 + 255) / 256 * 256;
-    PVS_TRY(ws_reserve(ctx, 6, cnt_b + (size_t)grid * cap * 8, reinterpret_cast<void**>(&ws)));
+    // uint8 rows: the prefilter forms every row's sum anyway and leaves (sum + 1e-7, 1 / that) for the aggregate pass,
+    // which then converts elements without a reduction and a division per member row
+    const bool stat = rowstat_out != nullptr && kind == PVS_DESC_U8_ROOTSIFT;
+    const size_t list_b = ((size_t)grid * cap * 8 + 255) / 256 * 256;
+    PVS_TRY(ws_reserve(ctx, 6, cnt_b + list_b + (stat ? (size_t)total * sizeof(float2) : 0), reinterpret_cast<void**>(&ws)));
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(ws);
     int64_t* rows = reinterpret_cast<int64_t*>(ws + cnt_b);
+    float2* rowstat = stat ? reinterpret_cast<float2*>(ws + cnt_b + list_b) : nullptr;
+    if (stat) *rowstat_out = rowstat;
     Assign16Args p{d_desc, total, cb->D, ld, static_cast<const _Float16*>(cb->d_c16), cb->d_cnorm, cb->K_pad, cb->D_pad16,
-                   cb->c16_shift, cb->cmax, static_cast<const _Float16*>(cb->d_cnk), cb->cn_e1, cb->K, d_labels, rows, cnt, cap};
+                   cb->c16_shift, cb->cmax, static_cast<const _Float16*>(cb->d_cnk), cb->cn_e1, cb->K, d_labels, rows, cnt, cap, rowstat};
     const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4 + (size_t)cb->K_pad * 8;
     PVS_TRY(launch_assign16(ctx, p, kind, cb->K_pad / 32, vec, lds16, grid));
     a.rows = rows;
@@ -631,29 +642,20 @@ struct AggArgs {
   float norm_p;
   float* out;              // [n_images][K*D]
   float* inv_norm;         // [n_images] or null
+  const float2* rowstat;   // uint8 rows: (row sum + 1e-7, reciprocal) per descriptor from the assignment pass, or null
 };
 
 constexpr int AGG_THREADS = 256;
 constexpr int AGG_WAVES = AGG_THREADS / 64;
 constexpr int AGG_CHUNK = 4096;  // descriptors sorted per pass (u16 indices in LDS)
 
-__device__ __forceinline__ float power_norm(float v, float p) {
-  // np.sign(v) * np.abs(v) ** p  (vlad.py:106); p == 1 and p == 0.5 take exact paths
-  if (p == 1.f) return v;
-  const float a = fabsf(v);
-  const float m = (p == 0.5f) ? sqrtf(a) : powf(a, p);
-  return v > 0.f ? m : (v < 0.f ? -m : (v == 0.f ? 0.f * m : v));
-}
-
-__device__ __forceinline__ float norm_accum(float v, int mode, float p) {
-  const float a = fabsf(v);
-  return mode == 2 ? v * v : (mode == 1 ? a : (mode == 3 ? a : powf(a, p)));
-}
-
 // One workgroup per image.  GROUP lanes cooperate on one cluster row; each lane owns NREG vectors of
 // VW consecutive dims: dims (r*GROUP + gl)*VW ... for r < NREG.
-template <int KIND, int GROUP, int VW, int NREG>
-__global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) {
+// HIOCC (short images: a few rows per cluster): the member loop is then a chain of dependent L2 / HBM round trips per cluster,
+// bound by how many workgroups a CU holds -- 64 registers let eight waves share a SIMD instead of five (batches of 4 rows).
+// Long images prefer batches of 8 rows at five waves per SIMD.  Same arithmetic, same order: the same bits either way.
+template <int KIND, int GROUP, int VW, int NREG, bool HIOCC = false>
+__global__ __launch_bounds__(AGG_THREADS, (HIOCC ? 8 : 1)) void vlad_aggregate_kernel(AggArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int K = a.K, D = a.D;
   int* hist = reinterpret_cast<int*>(smem);              // [AGG_WAVES][K]  counts, then cursors
@@ -763,14 +765,46 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
           acc[r][q] = (ch > 0 && in) ? out_img[(int64_t)k * D + d0 + q] : 0.f;  // continue a long image
         }
       }
-      // members in descriptor order; the loads of up to PF rows are issued before the first of them is added (one load in
-      // flight per lane group leaves the kernel latency-bound), the additions themselves stay strictly in order
-      // (the fused-RootSIFT kinds do a row reduction + sqrt per member: deeper batching only adds register pressure there)
-      constexpr int PF = DescTraits<KIND>::rootsift ? 2 : (NREG == 1 ? 8 : (NREG == 2 ? 4 : 2));
-      for (int p0 = s; p0 < e; p0 += PF) {
-        float x[PF][NREG][VW];
+      // members in descriptor order; the loads of a batch of rows are issued before the first of them is added (one load in
+      // flight per lane group leaves the kernel latency-bound), the additions themselves stay strictly in order.  The batch
+      // is as long as the rows left (8 / 4 / 2): with 512 rows over 256 clusters most clusters have one to three members,
+      // and this loop is instruction-bound -- slots of a batch that hold no row still cost their address arithmetic.
+      constexpr bool PACKED = KIND == PVS_DESC_U8_ROOTSIFT && VW == 4 && NREG == 1;
+      constexpr int PFMAX = HIOCC ? (DescTraits<KIND>::rootsift && !PACKED ? 2 : 4)
+                                  : (PACKED ? 8 : (DescTraits<KIND>::rootsift ? 2 : (NREG == 1 ? 8 : (NREG == 2 ? 4 : 2))));
+      const bool packed = PACKED && a.rowstat != nullptr;
+      auto batch = [&](auto nc, int p0) {
+        constexpr int N = decltype(nc)::value;
+        if constexpr (PACKED) {
+          if (packed) {
+            // uint8 rows with the row statistics of the assignment pass: a member row is ONE register per lane until it is
+            // converted, and the conversion needs neither the 32-lane reduction nor the division per row.  Same (d, r), same
+            // arithmetic: the same bits as the general branch.
+            const int d0 = gl * 4;
+            uint32_t w[N];
+            float2 st[N];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
+            for (int u = 0; u < N; ++u) {
+              const int64_t row = cbase + order[p0 + u < e ? p0 + u : p0];
+              w[u] = d0 < D ? *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a.X) + row * a.ld + d0) : 0u;
+              st[u] = a.rowstat[row];
+            }
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+              if (p0 + u < e) {   // uniform over the lane group
+                const RootsiftRow<KIND> rr(st[u].x, st[u].y);
+                acc[0][0] += (rr(float(w[u] & 0xffu)) - c[0][0]);
+                acc[0][1] += (rr(float((w[u] >> 8) & 0xffu)) - c[0][1]);
+                acc[0][2] += (rr(float((w[u] >> 16) & 0xffu)) - c[0][2]);
+                acc[0][3] += (rr(float(w[u] >> 24)) - c[0][3]);
+              }
+            }
+            return;
+          }
+        }
+        float x[N][NREG][VW];
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
           const bool live = p0 + u < e;
           const int64_t row = cbase + order[live ? p0 + u : p0];
 #pragma unroll
@@ -786,7 +820,7 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
           }
         }
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
+        for (int u = 0; u < N; ++u) {
           if (p0 + u < e) {   // uniform over the lane group
             if constexpr (DescTraits<KIND>::rootsift) {
               float sm = 0.f;
@@ -807,6 +841,16 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
               for (int q = 0; q < VW; ++q) acc[r][q] += (x[u][r][q] - c[r][q]);
           }
         }
+      };
+      {
+        int p0 = s;
+        if constexpr (PFMAX >= 8) {
+          for (; e - p0 > 4; p0 += 8) batch(std::integral_constant<int, 8>{}, p0);
+        }
+        if constexpr (PFMAX >= 4) {
+          for (; e - p0 > 2; p0 += 4) batch(std::integral_constant<int, 4>{}, p0);
+        }
+        for (; p0 < e; p0 += 2) batch(std::integral_constant<int, 2>{}, p0);
       }
 
       if (!last) {
@@ -843,10 +887,15 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
           const float t = norm_accum(acc[r][q], a.norm_mode, a.norm_p);
           part = a.norm_mode == 3 ? fmaxf(part, t) : part + t;
         }
-      float nrm = a.norm_mode == 3 ? wave_max_xor(part, GROUP) : wave_sum_xor(part, GROUP);
-      if (a.norm_mode == 2) nrm = sqrtf(nrm);
+      float nrm;
+      if constexpr (GROUP == 32) nrm = a.norm_mode == 3 ? half_max_xor(part) : half_sum_xor(part);   // same pairs as the shuffle butterfly: same bits
+      else nrm = a.norm_mode == 3 ? wave_max_xor(part, GROUP) : wave_sum_xor(part, GROUP);
+      if (a.norm_mode == 2) nrm = sqrt_rn(nrm);
       else if (a.norm_mode == 0) nrm = powf(nrm, 1.f / a.norm_p);
       const float den = nrm + a.eps;
+      // |acc| <= nrm <= den; after the square-root power norm a non-zero |acc| is >= 2^-75 and a zero is +0: no per-element guard
+      const DivByRow dv(den);
+      const bool dguard = a.power != 0.5f;
       float sq = 0.f;
 #pragma unroll
       for (int r = 0; r < NREG; ++r) {
@@ -854,7 +903,7 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
         float o[VW];
 #pragma unroll
         for (int q = 0; q < VW; ++q) {
-          o[q] = acc[r][q] / den;
+          o[q] = dv(acc[r][q], dguard);
           if (d0 + q < D) sq += o[q] * o[q];
         }
         if constexpr (VW == 4) {
@@ -863,7 +912,8 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(AggArgs a) 
           if (d0 < D) out_img[(int64_t)k * D + d0] = o[0];
         }
       }
-      sq = wave_sum_xor(sq, GROUP);
+      if constexpr (GROUP == 32) sq = half_sum_xor(sq);
+      else sq = wave_sum_xor(sq, GROUP);
       if (gl == 0) rowsq[k] = sq;
     }
     __syncthreads();
@@ -1044,18 +1094,20 @@ __global__ __launch_bounds__(ST_THREADS) void vlad_stream_kernel(AggArgs a) {
       const float t = norm_accum(v[q], a.norm_mode, a.norm_p);
       part = a.norm_mode == 3 ? fmaxf(part, t) : part + t;
     }
-    float nrm = a.norm_mode == 3 ? wave_max_xor(part, 32) : wave_sum_xor(part, 32);
-    if (a.norm_mode == 2) nrm = sqrtf(nrm);
+    float nrm = a.norm_mode == 3 ? half_max_xor(part) : half_sum_xor(part);
+    if (a.norm_mode == 2) nrm = sqrt_rn(nrm);
     else if (a.norm_mode == 0) nrm = powf(nrm, 1.f / a.norm_p);
     const float den = nrm + a.eps;
+    const DivByRow dv(den);
+    const bool dguard = a.power != 0.5f;
     float sq = 0.f, o[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      o[q] = v[q] / den;
+      o[q] = dv(v[q], dguard);
       if (dlive) sq += o[q] * o[q];
     }
     if (dlive) *reinterpret_cast<float4*>(out_img + (int64_t)k * D + d0) = make_float4(o[0], o[1], o[2], o[3]);
-    sq = wave_sum_xor(sq, 32);
+    sq = half_sum_xor(sq);
     if (gl == 0) rowsq[k] = sq;
   }
   __syncthreads();
@@ -1076,9 +1128,9 @@ static int launch_stream_inst(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, 
   return PVS_OK;
 }
 
-template <int KIND, int GROUP, int VW, int NREG>
+template <int KIND, int GROUP, int VW, int NREG, bool HIOCC = false>
 static int launch_agg_inst(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, size_t lds) {
-  auto k = vlad_aggregate_kernel<KIND, GROUP, VW, NREG>;
+  auto k = vlad_aggregate_kernel<KIND, GROUP, VW, NREG, HIOCC>;
   PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds));
   hipLaunchKernelGGL(k, dim3((unsigned)n_images), dim3(AGG_THREADS), lds, ctx->stream, a);
@@ -1087,10 +1139,11 @@ static int launch_agg_inst(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, siz
 }
 
 template <int KIND>
-static int launch_agg_kind(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, size_t lds, bool vec) {
+static int launch_agg_kind(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, size_t lds, bool vec, bool short_images) {
   const int D = a.D;
   if (vec) {  // 32 lanes x float4 = 128 dims per register step
     const int nreg = (D + 127) / 128;
+    if (nreg <= 1 && short_images) return launch_agg_inst<KIND, 32, 4, 1, true>(ctx, a, n_images, lds);
     if (nreg <= 1) return launch_agg_inst<KIND, 32, 4, 1>(ctx, a, n_images, lds);
     if (nreg <= 2) return launch_agg_inst<KIND, 32, 4, 2>(ctx, a, n_images, lds);
     if (nreg <= 4) return launch_agg_inst<KIND, 32, 4, 4>(ctx, a, n_images, lds);
@@ -1107,7 +1160,8 @@ static int launch_agg_kind(pvs_ctx* ctx, const AggArgs& a, int64_t n_images, siz
 
 int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int kind, int ld,
                           const int64_t* d_offsets, int64_t n_images, const int32_t* d_labels,
-                          const pvs_norm_params& prm, float* d_out, float* d_inv_norm, bool raw) {
+                          const pvs_norm_params& prm, float* d_out, float* d_inv_norm, bool raw, const float2* rowstat,
+                          int64_t total_hint) {
   if (n_images <= 0) return PVS_OK;
   if (cb->K > 2048) PVS_FAIL(PVS_ERR_UNSUPPORTED, "K = %d exceeds the VLAD aggregate kernel limit (2048)", cb->K);
   if (n_images > 0x7fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "too many images in one call");
@@ -1119,6 +1173,7 @@ int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_de
   a.norm_mode = raw ? 4 : (std::isinf(ord) ? 3 : (ord == 2.0 ? 2 : (ord == 1.0 ? 1 : 0)));
   a.norm_p = (float)ord;
   a.out = d_out; a.inv_norm = d_inv_norm;
+  a.rowstat = kind == PVS_DESC_U8_ROOTSIFT ? rowstat : nullptr;
   const int esz = kind == PVS_DESC_U8_ROOTSIFT ? 1 : 4;
   const bool vec = (cb->D % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_desc) % (4 * esz)) == 0) &&
                    ((reinterpret_cast<uintptr_t>(d_out) % 16) == 0);
@@ -1136,10 +1191,12 @@ int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_de
       default: PVS_FAIL(PVS_ERR_INVALID, "unknown descriptor kind %d", kind);
     }
   }
+  // fewer than ~3.5 rows per cluster on average (when the caller knows the row count): the eight-waves-per-SIMD variant
+  const bool short_images = total_hint > 0 && (double)total_hint < 3.5 * (double)n_images * (double)cb->K;
   switch (kind) {
-    case PVS_DESC_F32: return launch_agg_kind<PVS_DESC_F32>(ctx, a, n_images, lds, vec);
-    case PVS_DESC_F32_ROOTSIFT: return launch_agg_kind<PVS_DESC_F32_ROOTSIFT>(ctx, a, n_images, lds, vec);
-    case PVS_DESC_U8_ROOTSIFT: return launch_agg_kind<PVS_DESC_U8_ROOTSIFT>(ctx, a, n_images, lds, vec);
+    case PVS_DESC_F32: return launch_agg_kind<PVS_DESC_F32>(ctx, a, n_images, lds, vec, short_images);
+    case PVS_DESC_F32_ROOTSIFT: return launch_agg_kind<PVS_DESC_F32_ROOTSIFT>(ctx, a, n_images, lds, vec, short_images);
+    case PVS_DESC_U8_ROOTSIFT: return launch_agg_kind<PVS_DESC_U8_ROOTSIFT>(ctx, a, n_images, lds, vec, short_images);
     default: PVS_FAIL(PVS_ERR_INVALID, "unknown descriptor kind %d", kind);
   }
 }

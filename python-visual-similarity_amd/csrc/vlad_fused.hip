@@ -82,18 +82,6 @@ struct FusedArgs {
   unsigned long long* stamps;   // diagnostic build only: [16] cycle / event totals over all workgroups (pvs_fused_profile)
 };
 
-__device__ __forceinline__ float fu_power_norm(float v, float p) {
-  // identical to power_norm() of vlad.hip (np.sign(v) * np.abs(v) ** p)
-  if (p == 1.f) return v;
-  const float a = fabsf(v);
-  const float m = (p == 0.5f) ? sqrtf(a) : powf(a, p);
-  return v > 0.f ? m : (v < 0.f ? -m : (v == 0.f ? 0.f * m : v));
-}
-__device__ __forceinline__ float fu_norm_accum(float v, int mode, float p) {
-  const float a = fabsf(v);
-  return mode == 2 ? v * v : (mode == 1 ? a : (mode == 3 ? a : powf(a, p)));
-}
-
 template <int KIND>
 struct FuStage {   // the staged rows of one lane: 4 rows x 4 dims
   float4 v[4];
@@ -504,18 +492,20 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
           float part = 0.f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            v[q] = fu_power_norm(v[q], a.power);
-            const float tt = fu_norm_accum(v[q], a.norm_mode, a.norm_p);
+            v[q] = power_norm(v[q], a.power);
+            const float tt = norm_accum(v[q], a.norm_mode, a.norm_p);
             part = a.norm_mode == 3 ? fmaxf(part, tt) : part + tt;
           }
           float nrm = a.norm_mode == 3 ? half_max_xor(part) : half_sum_xor(part);   // the gather kernel's butterfly, bit for bit
-          if (a.norm_mode == 2) nrm = sqrtf(nrm);
+          if (a.norm_mode == 2) nrm = sqrt_rn(nrm);
           else if (a.norm_mode == 0) nrm = powf(nrm, 1.f / a.norm_p);
           const float den = nrm + a.eps;
+          const DivByRow dv(den);
+          const bool dguard = a.power != 0.5f;
           float sq = 0.f, o[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            o[q] = v[q] / den;
+            o[q] = dv(v[q], dguard);
             sq += o[q] * o[q];
           }
           if (k < a.K) *reinterpret_cast<float4*>(out_img + (int64_t)k * 128 + 4 * j) = make_float4(o[0], o[1], o[2], o[3]);

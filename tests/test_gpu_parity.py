@@ -741,7 +741,7 @@ def test_filtered_topk_is_bit_identical_to_the_exact_path(gpu_ctx, tables, case)
         assert st["redone_exact"] == {"ties_and_near_ties": 3}.get(case, 0), st
 
 
-@pytest.mark.parametrize("kind", [DESC_F32, DESC_U8_ROOTSIFT])
+@pytest.mark.parametrize("kind", [DESC_F32, DESC_U8_ROOTSIFT, DESC_F32_ROOTSIFT])
 def test_prefiltered_assignment_equals_the_exact_kernel(gpu_ctx, tables, kind, monkeypatch):
     """K1 runs an fp16 MFMA prefilter and sends only near ties to the exact fp32 kernel: the labels must be those of the
     exact kernel alone, for every descriptor -- incl. duplicated centres (exact ties), non-finite rows and zero rows."""
@@ -758,8 +758,21 @@ def test_prefiltered_assignment_equals_the_exact_kernel(gpu_ctx, tables, kind, m
         x[7, 9] = np.inf
         x[8] = C[100]                                 # a descriptor sitting on a centre
         x[9] = 0.5 * (C[3] + C[4])                    # and one between two centres
+    elif kind == DESC_F32_ROOTSIFT:
+        # raw float rows (non-integer, every scale): the prefilter converts them approximately, the exact kernel exactly
+        x = (raw * rng.uniform(1e-3, 1e3, size=(len(raw), 1))).astype(np.float32)
+        x[5] = 0.0
+        x[6, 3] = np.nan
+        x[7, 9] = np.inf
+        x[8, 4] = -3.0                                # sqrt of a negative element: NaN in the reference too
+        x[9] = 1e-30 * raw[9]                         # quotient denormal
+        x[10] = 1e30 * raw[10]
     else:
         x = raw.astype(np.uint8)
+        x[5] = 0
+        x[6] = 255                                    # the largest row sum
+        x[7] = 0
+        x[7, 77] = 1                                  # the smallest non-zero row
     off = np.array([0, len(x)], np.int64)
     with gpu_ctx.option(_ffi.OPT_ASSIGN_PREFILTER, 0):
         _, exact = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
@@ -1088,3 +1101,17 @@ def test_fused_encode_labels_equal_the_exact_kernel_on_many_rows(gpu_ctx, tables
             gpu_ctx.sync()
         labs.append(lab.cpu().numpy())
     assert np.array_equal(labs[0], labs[1]), (np.argwhere(labs[0] != labs[1])[:10], int((labs[0] != labs[1]).sum()))
+
+
+def test_short_sqrt_and_division_are_the_ieee_results():
+    """The VLAD normalisation epilogue takes its square root and its division by the cluster norm from short instruction
+    sequences (desc_load.hpp: sqrt_rn, DivByRow).  The device-side checker compares them with the compiler's IEEE sqrtf / division:
+    every one of the 2^32 float bit patterns for the root; 2e10 dividend / divisor pairs incl. the edge patterns, the guarded
+    fallbacks and the unguarded call of the epilogue for the division.  Bit for bit."""
+    import os, subprocess
+    from conftest import REPO
+    exe = os.path.join(REPO, "python-visual-similarity_amd", "csrc", "bench", "exact_sqrt_div")
+    assert os.path.exists(exe), "csrc/bench/exact_sqrt_div is built by `make` in csrc (see __graft_entry__.build)"
+    r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL EQUAL" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "over all 2^32 bit patterns: 0 differ" in r.stdout
