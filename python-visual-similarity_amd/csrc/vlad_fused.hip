@@ -492,20 +492,18 @@ __global__ __launch_bounds__(FU_THREADS, 2) void vlad_fused_kernel(FusedArgs a) 
           float part = 0.f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            v[q] = power_norm(v[q], a.power);
+            v[q] = power_norm<false>(v[q], a.power);
             const float tt = norm_accum(v[q], a.norm_mode, a.norm_p);
             part = a.norm_mode == 3 ? fmaxf(part, tt) : part + tt;
           }
           float nrm = a.norm_mode == 3 ? half_max_xor(part) : half_sum_xor(part);   // the gather kernel's butterfly, bit for bit
-          if (a.norm_mode == 2) nrm = sqrt_rn(nrm);
+          if (a.norm_mode == 2) nrm = sqrtf(nrm);
           else if (a.norm_mode == 0) nrm = powf(nrm, 1.f / a.norm_p);
           const float den = nrm + a.eps;
-          const DivByRow dv(den);
-          const bool dguard = a.power != 0.5f;
           float sq = 0.f, o[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            o[q] = dv(v[q], dguard);
+            o[q] = v[q] / den;      // (IEEE forms here, the short forms of desc_load.hpp in the gather kernel: the same bits)
             sq += o[q] * o[q];
           }
           if (k < a.K) *reinterpret_cast<float4*>(out_img + (int64_t)k * 128 + 4 * j) = make_float4(o[0], o[1], o[2], o[3]);
