@@ -12,7 +12,9 @@ if [ "$part" = "1" ]; then
   bash profiles/collect.sh r02 vlad512_u8 --workload vlad512 --images 32768 --desc u8 > gpurun_out/collect_vlad512_u8.log 2>&1; echo vlad512 u8 done
   python3 tests/tools/fused_profile.py 16384 f32 > gpurun_out/fp_f32.json 2> gpurun_out/fp_f32.err
   python3 tests/tools/fused_profile.py 16384 u8 > gpurun_out/fp_u8.json 2> gpurun_out/fp_u8.err
-  cat gpurun_out/fp_f32.json gpurun_out/fp_u8.json
+  python3 tests/tools/assign_profile.py 16384 f32 > gpurun_out/ap_f32.json 2> gpurun_out/ap_f32.err
+  python3 tests/tools/assign_profile.py 16384 u8 > gpurun_out/ap_u8.json 2> gpurun_out/ap_u8.err
+  cat gpurun_out/fp_f32.json gpurun_out/fp_u8.json gpurun_out/ap_f32.json gpurun_out/ap_u8.json
 elif [ "$part" = "2" ]; then
   bash profiles/collect.sh r02 fisher --workload fisher > gpurun_out/collect_fisher.log 2>&1; echo fisher done
   bash profiles/collect.sh r02 fp16sim --workload fp16sim --images 32768 > gpurun_out/collect_fp16sim.log 2>&1; echo fp16sim done

@@ -211,12 +211,13 @@ struct Assign16Args {
   unsigned long long* amb_count; // [gridDim]
   int64_t cap;
   float2* rowstat;               // uint8 rows: (row sum + 1e-7, its reciprocal) per descriptor for the aggregate pass, or null
+  unsigned long long* stamps;    // diagnostic build (DIAG) only: [16] cycle totals over all workgroups, see pvs_fused_profile
 };
 
 // STEPS: the number of 16-dim k-steps when it is known at compile time (8 for D_pad16 = 128), 0 = read it from the arguments.
 // With STEPS > 0 the whole cluster loop of a row block is straight-line code: table fragments are fetched from LDS one step
 // ahead of the MFMAs that use them, and the selection over one pair of tiles runs under the MFMAs of the next pair.
-template <int NT, int KIND, bool VEC, int STEPS>
+template <int NT, int KIND, bool VEC, int STEPS, bool DIAG = false>
 __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned int s_count;
@@ -264,7 +265,20 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
     if (blockIdx.x < nblocks) request_rows(blockIdx.x);
   }
 
+  // STEPS > 0: ping-pong.  The 8 waves are two groups (waves 0-3 / 4-7: one wave of each per SIMD).  A row block is
+  //   [conversion (+ the previous block's tail) | barrier | MFMA loop | barrier]
+  // and group 1 runs one barrier behind group 0, so that on every SIMD one wave feeds the matrix pipe while the other does its
+  // vector work (conversion: fp32 multiplies / subtracts that do block the pipe when they come from the SAME phase on both
+  // waves; left to drift, the two waves of a SIMD spent a third of the time converting together with the pipe idle: 69 % busy).
+  // All waves of a workgroup run the same number of blocks, so the barrier counts match.
+  constexpr bool PP = STEPS > 0;
+  const bool pp_g1 = wave >= ASSIGN_THREADS / 128;
+  if constexpr (PP) {
+    if (pp_g1) __builtin_amdgcn_s_barrier();
+  }
+  unsigned long long dg[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0, dt1 = 0, dt2 = 0, dt3 = 0, dt4 = 0;
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    if constexpr (DIAG) dt0 = __builtin_amdgcn_s_memtime();
     const int64_t row = blk * ASSIGN_ROWS + wave * 32 + j;
     const bool rvalid = row < a.total;
     // ---- this lane's half of the row: of every 16 dims the four at 4h and the four at 8 + 4h (the lane pair (j, 0), (j, 1)
@@ -365,6 +379,9 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
       if (blk + gridDim.x < nblocks) request_rows(blk + gridDim.x);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (DIAG) dt1 = __builtin_amdgcn_s_memtime();
+    if constexpr (PP) __builtin_amdgcn_s_barrier();
+    if constexpr (DIAG) dt2 = __builtin_amdgcn_s_memtime();
     if constexpr (STEPS > 0) {
       constexpr int G2 = NT < 2 ? NT : 2;     // tiles per group: two accumulator sets alternate between groups
       constexpr int NG = NT / G2;
@@ -490,6 +507,9 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
         }
     }
     }
+    if constexpr (DIAG) dt3 = __builtin_amdgcn_s_memtime();
+    if constexpr (PP) __builtin_amdgcn_s_barrier();
+    if constexpr (DIAG) dt4 = __builtin_amdgcn_s_memtime();
     bidx += 4 * h;
     {   // the two half-waves hold interleaved cluster subsets of the same descriptor
       const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
@@ -517,6 +537,20 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
     if (h == 0 && rvalid) {
       if (settled) a.labels[row] = bidx;
       else my_rows[base + __popcll(amask & ((1ull << lane) - 1ull))] = row;
+    }
+    if constexpr (DIAG) {
+      const unsigned long long dt5 = __builtin_amdgcn_s_memtime();
+      dg[0] += dt1 - dt0; dg[1] += dt2 - dt1; dg[2] += dt3 - dt2; dg[3] += dt4 - dt3; dg[4] += dt5 - dt4; dg[5] += 1;
+    }
+  }
+  if constexpr (PP) {
+    if (!pp_g1) __builtin_amdgcn_s_barrier();
+  }
+  if constexpr (DIAG) {   // waves 0 (group 0) and 4 (group 1): [0..4] / [5..9] conversion, barrier, MFMA loop, barrier, tail; [10] blocks
+    if (a.stamps != nullptr && lane == 0 && (wave == 0 || wave == 4)) {
+      const int o = wave == 0 ? 0 : 5;
+      for (int q = 0; q < 5; ++q) atomicAdd(a.stamps + o + q, dg[q]);
+      if (wave == 0) atomicAdd(a.stamps + 10, dg[5]);
     }
   }
   __syncthreads();
@@ -551,6 +585,9 @@ static int launch_assign16_nt(pvs_ctx* ctx, const Assign16Args& p, bool vec, siz
   auto ks = assign16_kernel<NT, KIND, false, 0>;
   auto k8 = assign16_kernel<NT, KIND, true, 8>;
   auto k = vec ? (p.D == 128 && p.D_pad16 == 128 ? k8 : kv) : ks;
+  if constexpr (NT == 8) {   // pvs_fused_profile(ctx, 1, ...): the stamped build of the shape the benchmarks use
+    if (p.stamps != nullptr && k == k8) k = assign16_kernel<NT, KIND, true, 8, true>;
+  }
   PVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(grid), dim3(ASSIGN_THREADS), lds, ctx->stream, p);
   PVS_HIP(hipGetLastError());
@@ -614,7 +651,8 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
     float2* rowstat = stat ? reinterpret_cast<float2*>(ws + cnt_b + list_b) : nullptr;
     if (stat) *rowstat_out = rowstat;
     Assign16Args p{d_desc, total, cb->D, ld, static_cast<const _Float16*>(cb->d_c16), cb->d_cnorm, cb->K_pad, cb->D_pad16,
-                   cb->c16_shift, cb->cmax, static_cast<const _Float16*>(cb->d_cnk), cb->cn_e1, cb->K, d_labels, rows, cnt, cap, rowstat};
+                   cb->c16_shift, cb->cmax, static_cast<const _Float16*>(cb->d_cnk), cb->cn_e1, cb->K, d_labels, rows, cnt, cap, rowstat,
+                   ctx->d_fused_stamps};
     const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4 + (size_t)cb->K_pad * 8;
     PVS_TRY(launch_assign16(ctx, p, kind, cb->K_pad / 32, vec, lds16, grid));
     a.rows = rows;

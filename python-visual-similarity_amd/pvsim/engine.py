@@ -426,10 +426,13 @@ class Context:
         check(_ffi.lib().pvs_min_update_dev(self.handle, ptr(d_mind), ptr(d_dist), total_desc, ptr(bs)))
         return bs
 
-    def fused_profile(self, enable=True):
-        """pvs_fused_profile: (re)start or stop the stamped diagnostic build of the fused VLAD encode -> the 16 counters so far."""
+    def fused_profile(self, enable=True, raw=False):
+        """pvs_fused_profile: (re)start or stop the stamped diagnostic builds of the VLAD encode kernels -> the 16 counters so far
+        (fused path: the names below; two-kernel path with raw=True: the prefilter's phase cycles, see tests/tools/assign_profile.py)."""
         out = np.zeros(16, dtype=np.int64)
         check(_ffi.lib().pvs_fused_profile(self.handle, int(enable), ptr(out)))
+        if raw:
+            return out
         names = ("P0", "A", "reduce", "reevaluate", "K2", "epilogue", "image_switch", "_", "stages", "stages_reevaluated", "entries", "rows_unsettled")
         return {n: int(v) for n, v in zip(names, out) if n != "_"}
 
