@@ -28,7 +28,7 @@ if stats:
             r[0] = r[0][:110]
             w.writerow(r)
 out = {}
-for name, pattern in (("FETCH_SIZE_KiB", "fetch/**/*_counter_collection.csv"),
+for cname, pattern in (("FETCH_SIZE_KiB", "fetch/**/*_counter_collection.csv"),
                       ("WRITE_SIZE_KiB", "write/**/*_counter_collection.csv")):
     path = one(pattern)
     if not path:
@@ -38,7 +38,7 @@ for name, pattern in (("FETCH_SIZE_KiB", "fetch/**/*_counter_collection.csv"),
         if "pvs::" in r["Kernel_Name"]:
             agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        out.setdefault(k, {})[name] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+        out.setdefault(k, {})[cname] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
 for k, d in out.items():
     if "FETCH_SIZE_KiB" in d and "WRITE_SIZE_KiB" in d:
         f_, w_ = d["FETCH_SIZE_KiB"]["mean_per_launch"], d["WRITE_SIZE_KiB"]["mean_per_launch"]
