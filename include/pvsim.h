@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PVS_VERSION 101 /* 0.1.1 */
+#define PVS_VERSION 102 /* 0.1.2 */
 
 typedef enum {
   PVS_OK = 0,
@@ -56,7 +56,9 @@ typedef enum {
   PVS_OPT_VLAD_PATH = 1,        /* 0 (default) and 1: assign + gather aggregate (two reads of the descriptors); 2: assign +        */
                                 /* streaming aggregate; 3: fused one-read kernel (D = 128, 128 < K <= 256; error otherwise)        */
   PVS_OPT_TOPK_SELECT_ONLY = 2, /* 0 (default): k <= 16 takes the k-rounds kernel; 1: always the radix-select kernel               */
-  PVS_OPT_COUNT_ = 3
+  PVS_OPT_AGG_VARIANT = 3,      /* gather aggregate at D <= 128: 0 (default) chosen by rows per cluster; 1: eight waves per SIMD,     */
+                                /* batches of 4 rows (short images); 2: five waves, batches of 8 (long images).  Same bits.         */
+  PVS_OPT_COUNT_ = 4
 } pvs_option;
 
 typedef struct pvs_ctx pvs_ctx;

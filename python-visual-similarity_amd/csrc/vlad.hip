@@ -1230,7 +1230,8 @@ int launch_vlad_aggregate(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_de
     }
   }
   // fewer than ~3.5 rows per cluster on average (when the caller knows the row count): the eight-waves-per-SIMD variant
-  const bool short_images = total_hint > 0 && (double)total_hint < 3.5 * (double)n_images * (double)cb->K;
+  const int variant = ctx->opt[PVS_OPT_AGG_VARIANT];
+  const bool short_images = variant == 1 || (variant != 2 && total_hint > 0 && (double)total_hint < 3.5 * (double)n_images * (double)cb->K);
   switch (kind) {
     case PVS_DESC_F32: return launch_agg_kind<PVS_DESC_F32>(ctx, a, n_images, lds, vec, short_images);
     case PVS_DESC_F32_ROOTSIFT: return launch_agg_kind<PVS_DESC_F32_ROOTSIFT>(ctx, a, n_images, lds, vec, short_images);

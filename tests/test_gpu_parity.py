@@ -775,10 +775,32 @@ def test_prefiltered_assignment_equals_the_exact_kernel(gpu_ctx, tables, kind, m
         x[7, 77] = 1                                  # the smallest non-zero row
     off = np.array([0, len(x)], np.int64)
     with gpu_ctx.option(_ffi.OPT_ASSIGN_PREFILTER, 0):
-        _, exact = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
-    _, pre = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
+        v_exact, exact = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
+    v_pre, pre = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
     assert np.array_equal(exact, pre), np.argwhere(exact != pre)[:10]
     assert not np.any(pre == 200)                    # never the later duplicate
+    # the encodings too, bit for bit: with the prefilter the aggregate pass of uint8 rows converts elements from the row
+    # statistics the prefilter leaves behind, without it from its own row reduction
+    assert v_exact.tobytes() == v_pre.tobytes()
+
+
+@pytest.mark.parametrize("kind", [DESC_F32, DESC_U8_ROOTSIFT])
+@pytest.mark.parametrize("rows", [(3, 40, 512, 0, 700, 64), (4100, 9000)])
+def test_aggregate_variants_give_the_same_bits(gpu_ctx, tables, kind, rows):
+    """The gather aggregate has two register budgets at D <= 128 (eight waves per SIMD with batches of 4 rows for short images,
+    five waves with batches of 8 for long ones; the launcher picks by rows per cluster).  Same arithmetic in the same order:
+    encodings, labels and 1 / norm must be bit-identical whichever runs, on short and on long images."""
+    rng = np.random.default_rng(5)
+    raws = [synth.sift_like(n, rng) for n in rows]
+    cb = gpu_ctx.codebook(tables["centroids"])
+    imgs = [r.astype(np.uint8) for r in raws] if kind == DESC_U8_ROOTSIFT else [synth.rootsift(r) for r in raws]
+    packed, off = pack_descriptors(imgs, 128, np.uint8 if kind == DESC_U8_ROOTSIFT else np.float32)
+    outs = []
+    for variant in (1, 2, 0):
+        with gpu_ctx.option(_ffi.OPT_AGG_VARIANT, variant):
+            v, lab = gpu_ctx.vlad_encode(cb, packed, off, kind, return_labels=True)
+        outs.append((v.tobytes(), lab.tobytes()))
+    assert outs[0] == outs[1] == outs[2]
 
 
 @pytest.mark.parametrize("K,D", [(40, 100), (64, 30), (256, 128), (17, 16), (130, 72)])

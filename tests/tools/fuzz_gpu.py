@@ -158,6 +158,13 @@ def case_learn():
                   "nan in device centres", bool(np.isnan(mi.cluster_centers_).any()), "nan in restatement centres", bool(np.isnan(ri[0]).any()),
                   "empty clusters device/restatement", int((np.bincount(mi.labels_, minlength=K) == 0).sum()),
                   int((np.bincount(ri[1], minlength=K) == 0).sum()), flush=True)
+        b0 = np.where(l0 != ref_l0)[0]
+        if len(b0):
+            d64 = ((x[b0].astype(np.float64)[:, None, :] - c0.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+            ds = np.sort(d64, axis=1)
+            print("DIAG step0 mismatching points", b0[:8], "fp64 gap between their two nearest centres", (ds[:, 1] - ds[:, 0])[:8],
+                  "scale |x||c|", (np.linalg.norm(x[b0], axis=1) * np.linalg.norm(c0, axis=1).max())[:8],
+                  "device label / restatement label / fp64 argmin", l0[b0][:8], ref_l0[b0][:8], d64.argmin(1)[:8], flush=True)
         print("DIAG step0: device labels == plain restatement", np.array_equal(l0, ref_l0), "== centred restatement", np.array_equal(l0, ref_l0c),
               "counts", counts, "restatement counts (centred)", np.bincount(ref_l0c, minlength=K), flush=True)
         print("DIAG labels: mismatches", len(bad), "margins of the mismatched points under the restatement's centres", gap[bad][:8],
