@@ -227,6 +227,11 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
   _Float16* lds_l = lds_h + CB * stride;
   float* lds_n = reinterpret_cast<float*>(lds_l + CB * stride);
   _Float16* lds_k = reinterpret_cast<_Float16*>(lds_n + CB);    // [CB][4]: the -|c|^2/2 pieces (STEPS > 0 only)
+  // uint8 rows (LUT): sqrt(raw) for raw = 0..255 as an fp16 pair (hi | lo << 16).  RootSIFT's element is sqrt(raw) / sqrt(d) with ONE
+  // factor per row, so the prefilter works on T = sqrt(raw) -- a table lookup and two byte permutes per element, no arithmetic
+  // at all -- and the row's factor sqrt(d) moves into the -|c|^2/2 step:  x.c - |c|^2/2 = (T.c - |c|^2 sqrt(d) / 2) / sqrt(d).
+  constexpr bool LUT = KIND == PVS_DESC_U8_ROOTSIFT && STEPS > 0 && VEC;
+  uint32_t* lds_t = reinterpret_cast<uint32_t*>(lds_k + 4 * CB);   // [256]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int nt = a.D_pad16 >> 4;      // k-steps of 16 dims
@@ -241,6 +246,13 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
   if constexpr (STEPS > 0)
     for (int idx = threadIdx.x; idx < CB; idx += ASSIGN_THREADS)
       *reinterpret_cast<uint2*>(lds_k + 4 * idx) = *reinterpret_cast<const uint2*>(a.cnk + 4 * idx);
+  if constexpr (LUT) {
+    if (threadIdx.x < 256) {
+      const float sv = sqrtf((float)threadIdx.x);
+      const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+      lds_t[threadIdx.x] = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+    }
+  }
   if (threadIdx.x == 0) s_count = 0u;
   __syncthreads();
   const float sqrt_d = sqrtf((float)a.D);
@@ -248,11 +260,21 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
 
   // STEPS > 0 (launched only for D = 128) with float rows: the rows of the NEXT block are requested before this block's MFMA
   // phase and land under it.  Loads are unconditional: a row past the end reads the last row instead, its result is not stored.
-  constexpr bool PREFETCH = STEPS > 0 && VEC && KIND != PVS_DESC_U8_ROOTSIFT;
+  constexpr bool PREFETCH = STEPS > 0 && VEC;
   float xf[8][8];
+  uint32_t xw[8][2];       // LUT: the raw bytes of this lane's half row
   auto request_rows = [&](int64_t blk_) {
     int64_t r = blk_ * ASSIGN_ROWS + wave * 32 + j;
     r = r < a.total ? r : a.total - 1;
+    if constexpr (LUT) {
+      const uint8_t* pr = static_cast<const uint8_t*>(a.X) + r * a.ld + 4 * h;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        xw[t][0] = *reinterpret_cast<const uint32_t*>(pr + 16 * t);
+        xw[t][1] = *reinterpret_cast<const uint32_t*>(pr + 16 * t + 8);
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const float4 v0 = load4<KIND>(a.X, r, a.ld, 16 * t + 4 * h);
@@ -309,6 +331,45 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
       }
     }
     }
+    float nx;
+    int x_shift = 0;
+    bool finite;
+    f16x8_t xh[8], xl[8];
+    _Float16 lut_f1 = (_Float16)0.f, lut_f2 = (_Float16)0.f;   // LUT: sqrt(d) 2^cn_e1 as two fp16 pieces (the row side of the -|c|^2/2 step)
+    float lut_sd = 1.f;                                        // LUT: sqrt(d): this row's scores and margins are in units of 1 / sqrt(d)
+    if constexpr (LUT) {
+      unsigned ssum = 0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        ssum = __builtin_amdgcn_sad_u8(xw[t][0], 0u, ssum);
+        ssum = __builtin_amdgcn_sad_u8(xw[t][1], 0u, ssum);
+      }
+      ssum += __shfl_xor(ssum, 32, 64);
+      const float sf = (float)ssum, dd = sf + 1e-7f;
+      if (a.rowstat != nullptr && h == 0 && rvalid) a.rowstat[row] = make_float2(dd, 1.0f / dd);   // = RootsiftRow(s), bit for bit
+      lut_sd = sqrtf(dd);
+      const float ff = ldexpf(lut_sd, a.cn_e1);
+      lut_f1 = (_Float16)ff;
+      lut_f2 = (_Float16)(ff - (float)lut_f1);
+      // f1 and f2 must be normal fp16 numbers (f2 ~ 2^-11 f1): 2^-3 <= f <= 2^15; all-zero rows (d = 1e-7) go to the exact kernel
+      finite = ff >= 0.125f && ff <= 32768.f;
+      nx = sqrtf(sf) * 1.0001f;              // |T| = sqrt(sum of the raw row), exactly
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        uint32_t hw[4], lw[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int pq = 0; pq < 2; ++pq) {
+            const uint32_t w = xw[t][i];
+            const uint32_t e0 = lds_t[(w >> (16 * pq)) & 0xffu], e1 = lds_t[(w >> (16 * pq + 8)) & 0xffu];
+            hw[2 * i + pq] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);   // hi(e0) | hi(e1) << 16
+            lw[2 * i + pq] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);   // lo(e0) | lo(e1) << 16
+          }
+        xh[t] = __builtin_bit_cast(f16x8_t, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+        xl[t] = __builtin_bit_cast(f16x8_t, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+      }
+    } else {
     // ---- row norm, row scale (largest |x| 2^shift in [2^12, 2^13)), hi / lo halves
     float n2 = 0.f, amax = 0.f, rs_r = 0.f;
     if constexpr (DescTraits<KIND>::rootsift) {
@@ -346,18 +407,17 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
       n2 += __shfl_xor(n2, 32, 64);
       amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
     }
-    const float nx = sqrtf(n2) * 1.0001f;
+    nx = sqrtf(n2) * 1.0001f;
     int ex = 13;
     if (amax > 0.f) (void)frexpf(amax, &ex);
-    int x_shift = 13 - ex;
-    bool finite = nx <= 3.0e38f;   // false for NaN too
+    x_shift = 13 - ex;
+    finite = nx <= 3.0e38f;   // false for NaN too
     if (x_shift > 40 || x_shift < -40) { finite = false; x_shift = 0; }
     if constexpr (STEPS > 0) {     // the row scale enters the -|c|^2/2 step as an fp16 factor: it must be a normal fp16 number
       if (x_shift + a.cn_e1 < -14 || x_shift + a.cn_e1 > 15) finite = false;
     }
     const float xs = ldexpf(1.f, x_shift);
     const float rs_rs = rs_r * xs * xs;     // rootsift kinds: sqrt(raw r) 2^shift = sqrt(raw r 4^shift), the scale is exact
-    f16x8_t xh[8], xl[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -369,9 +429,10 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
         xh[t][q] = hi;
         xl[t][q] = (_Float16)(v - (float)hi);
       }
+    }
     // ---- clusters in groups of G tiles (accumulators of one group live at a time): smallest and second smallest v16
     constexpr int G = NT < 4 ? NT : 4;
-    const float m2s = -2.f * ldexpf(1.f, -(x_shift + a.c_shift));   // v = cn - 2 acc 2^-(shifts): one fma, the scale is exact
+    const float m2s = -2.f * ldexpf(1.f, -(x_shift + a.c_shift));   // v = cn - 2 acc 2^-(shifts): one fma, the scale is exact (LUT: x_shift = 0, v in units of 1 / sqrt(d))
     float best = INFINITY, second = INFINITY;
     int bidx = 0;
     if constexpr (PREFETCH) {
@@ -417,7 +478,11 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
         const _Float16 pw = (h == 0 && finite) ? (_Float16)ldexpf(1.f, x_shift + a.cn_e1) : (_Float16)0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) cnb[q] = (_Float16)0.f;
-        cnb[0] = pw; cnb[1] = pw; cnb[2] = pw;
+        if constexpr (LUT) {   // six exact products: (three pieces of -|c|^2/2) x (two pieces of sqrt(d) 2^cn_e1)
+          if (h == 0 && finite) { cnb[0] = lut_f1; cnb[1] = lut_f2; cnb[2] = lut_f1; cnb[3] = lut_f2; cnb[4] = lut_f1; cnb[5] = lut_f2; }
+        } else {
+          cnb[0] = pw; cnb[1] = pw; cnb[2] = pw;
+        }
       }
       best = -INFINITY;
       second = -INFINITY;
@@ -426,20 +491,18 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int ab = g & 1;
-#pragma unroll
-        for (int tile = 0; tile < G2; ++tile)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[ab][tile][r] = 0.f;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < STEPS; ++t) {
           const int step = g * STEPS + t, buf = step & 1;
           if (step + 1 < NG * STEPS) fetch(buf ^ 1, step + 1);
           __builtin_amdgcn_sched_barrier(0);     // the fetch stays AHEAD of this step's MFMAs (the scheduler sinks it otherwise)
           // the three products of a tile go to the same accumulator in a fixed order; the tiles alternate so that an MFMA
-          // never waits for the result of the one issued just before it
+          // never waits for the result of the one issued just before it.  (The group's first MFMA takes the constant 0 as its
+          // accumulator input: no sixteen v_mov per tile to clear it.)
 #pragma unroll
           for (int tile = 0; tile < G2; ++tile)
-            acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[buf][tile], xh[t], acc[ab][tile], 0, 0, 0);
+            acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[buf][tile], xh[t], t == 0 ? zero16 : acc[ab][tile], 0, 0, 0);
 #pragma unroll
           for (int tile = 0; tile < G2; ++tile)
             acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[buf][tile], xl[t], acc[ab][tile], 0, 0, 0);
@@ -453,7 +516,11 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
               f16x8_t ca;
 #pragma unroll
               for (int q = 0; q < 8; ++q) ca[q] = (_Float16)0.f;
-              if (h == 0) { ca[0] = pk[0]; ca[1] = pk[1]; ca[2] = pk[2]; }
+              if constexpr (LUT) {
+                if (h == 0) { ca[0] = pk[0]; ca[1] = pk[0]; ca[2] = pk[1]; ca[3] = pk[1]; ca[4] = pk[2]; ca[5] = pk[2]; }
+              } else {
+                if (h == 0) { ca[0] = pk[0]; ca[1] = pk[1]; ca[2] = pk[2]; }
+              }
               acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, cnb, acc[ab][tile], 0, 0, 0);
             }
           }
@@ -522,7 +589,10 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
     }
     const float xc = nx * a.cmax;
     constexpr float conv_err = DescTraits<KIND>::rootsift ? 4.8e-7f : 0.f;   // 2^-21: the approximate RootSIFT elements above
-    const float eps = 2.f * (4.8e-7f + 2.4e-7f + 4.8e-5f + 7.7e-6f + 1e-9f + conv_err) * xc * (1.f + sqrt_d * 1e-9f) + 2.4e-7f * (a.cmax * a.cmax + 2.f * xc);
+    // LUT rows: everything in units of 1 / sqrt(d) (|T| |c| instead of |x| |c|; |c|^2 sqrt(d) instead of |c|^2); the -|c|^2/2 term
+    // additionally carries the dropped third piece of sqrt(d) (2^-22) and six accumulation roundings (6 2^-24): 6e-7 instead of 2.4e-7
+    const float cc = LUT ? a.cmax * a.cmax * lut_sd : a.cmax * a.cmax;
+    const float eps = 2.f * (4.8e-7f + 2.4e-7f + 4.8e-5f + 7.7e-6f + 1e-9f + conv_err) * xc * (1.f + sqrt_d * 1e-9f) + (LUT ? 6.0e-7f : 2.4e-7f) * (cc + 2.f * xc);
     const int within = second <= best + 2.f * eps ? 2 : 1;
     // settled: exactly one cluster within the margin (the minimum itself) and everything finite
     const bool settled = within == 1 && finite && fabsf(best) <= 3.0e38f && bidx < a.K;   // (a padded cluster never settles a row)
@@ -653,7 +723,7 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
     Assign16Args p{d_desc, total, cb->D, ld, static_cast<const _Float16*>(cb->d_c16), cb->d_cnorm, cb->K_pad, cb->D_pad16,
                    cb->c16_shift, cb->cmax, static_cast<const _Float16*>(cb->d_cnk), cb->cn_e1, cb->K, d_labels, rows, cnt, cap, rowstat,
                    ctx->d_fused_stamps};
-    const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4 + (size_t)cb->K_pad * 8;
+    const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4 + (size_t)cb->K_pad * 8 + 1024;   // + the sqrt table of uint8 rows
     PVS_TRY(launch_assign16(ctx, p, kind, cb->K_pad / 32, vec, lds16, grid));
     a.rows = rows;
     a.nrows = cnt;
