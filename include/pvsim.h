@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PVS_VERSION 102 /* 0.1.2 */
+#define PVS_VERSION 103 /* 0.1.3 */
 
 typedef enum {
   PVS_OK = 0,
@@ -261,6 +261,15 @@ int pvs_seed_pick_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc,
                       const double* h_base, const double* h_target, int n_cand, float* d_cand, int64_t* h_idx);
 /* d_mind = min(d_mind, d_dist) (d_dist NULL = keep) and h_block_sums[ceil(n/4096)] = fp64 sums of d_mind per 4096 entries. */
 int pvs_min_update_dev(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total_desc, double* h_block_sums);
+
+/* The whole greedy k-means++ run (sklearn/cluster/_kmeans.py:_kmeans_plusplus) from a given first centre, without a host round
+ * trip per step: for c = 1 .. n_clusters-1 the targets u * pot, the candidate draws (pvs_seed_pick_dev's arithmetic, the block of a
+ * draw found on the device), the candidates' distances and potentials, the best candidate and the running-minimum update are
+ * enqueued back to back; one synchronisation at the end.  trials <= 8 (2 + log K for K < 404).  h_uniform: (n_clusters-1) x trials
+ * numbers in [0, 1) from the caller's random stream, in draw order.  h_indices[n_clusters]: [0] = the first centre (in), the
+ * others out.  The same indices as the stepwise entry points give with the same numbers. */
+int pvs_kmeanspp_run_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, int n_clusters, int trials,
+                         const double* h_uniform, int64_t* h_indices);
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py) */
 /* Enable per-kernel-family HIP-event timing on the context's stream. which: 0 assign, 1 aggregate,

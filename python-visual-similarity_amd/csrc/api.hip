@@ -1100,6 +1100,39 @@ PVS_EXPORT int pvs_min_update_dev(pvs_ctx* ctx, float* d_mind, const float* d_di
   return stats_to_host(ctx, d_bs, nblk, h_block_sums);
 }
 
+PVS_EXPORT int pvs_kmeanspp_run_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_desc, int n_clusters, int trials,
+                                    const double* h_uniform, int64_t* h_indices) {
+  PVS_NEED(ctx, "ctx");
+  PVS_NEED(d_x, "descriptors");
+  PVS_NEED(h_uniform, "uniform numbers");
+  PVS_NEED(h_indices, "indices");
+  if (D <= 0 || total_desc <= 0 || n_clusters < 1 || n_clusters > total_desc) PVS_FAIL(PVS_ERR_INVALID, "sizes");
+  if (trials < 1 || trials > 8) PVS_FAIL(PVS_ERR_UNSUPPORTED, "1..8 local trials (got %d): use the stepwise entry points", trials);
+  if (h_indices[0] < 0 || h_indices[0] >= total_desc) PVS_FAIL(PVS_ERR_INVALID, "first centre out of range");
+  PVS_HIP(hipSetDevice(ctx->device));
+  const size_t nblk = (size_t)((total_desc + 4095) / 4096);
+  auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t mind_b = al((size_t)total_desc * 4), dist_b = al((size_t)trials * total_desc * 4), cand_b = al((size_t)trials * D * 4),
+               bs_b = al(nblk * 8), uni_b = al((size_t)std::max(n_clusters - 1, 1) * trials * 8), idx_b = al((size_t)n_clusters * 8), small_b = 512;
+  char* ws = nullptr;
+  PVS_TRY(ws_reserve(ctx, 3, mind_b + dist_b + cand_b + bs_b + uni_b + idx_b + small_b, reinterpret_cast<void**>(&ws)));
+  float* d_mind = reinterpret_cast<float*>(ws);
+  float* d_dist = reinterpret_cast<float*>(ws + mind_b);
+  float* d_cand = reinterpret_cast<float*>(ws + mind_b + dist_b);
+  double* d_bs = reinterpret_cast<double*>(ws + mind_b + dist_b + cand_b);
+  double* d_uni = reinterpret_cast<double*>(ws + mind_b + dist_b + cand_b + bs_b);
+  int64_t* d_indices = reinterpret_cast<int64_t*>(ws + mind_b + dist_b + cand_b + bs_b + uni_b);
+  char* d_small = ws + mind_b + dist_b + cand_b + bs_b + uni_b + idx_b;
+  PVS_HIP(hipMemsetAsync(d_mind, 0x7f, (size_t)total_desc * 4, ctx->stream));     // 3.39e38: "no centre yet"
+  if (n_clusters > 1)
+    PVS_HIP(hipMemcpyAsync(d_uni, h_uniform, (size_t)(n_clusters - 1) * trials * 8, hipMemcpyHostToDevice, ctx->stream));
+  PVS_HIP(hipMemcpyAsync(d_indices, h_indices, 8, hipMemcpyHostToDevice, ctx->stream));
+  PVS_TRY(launch_kmeanspp_run(ctx, d_x, total_desc, D, n_clusters, trials, d_uni, d_mind, d_dist, d_cand, d_bs, d_small, d_indices));
+  PVS_HIP(hipMemcpyAsync(h_indices, d_indices, (size_t)n_clusters * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PVS_HIP(hipStreamSynchronize(ctx->stream));
+  return PVS_OK;
+}
+
 // ================================================================================ diagnostics
 PVS_EXPORT int pvs_fused_profile(pvs_ctx* ctx, int enable, int64_t* out16) {
   PVS_NEED(ctx, "ctx");

@@ -426,8 +426,9 @@ int launch_seed_pick(pvs_ctx* ctx, const float* x, int64_t total, int D, const f
 // d_mind = min(d_mind, d_dist) and the fp64 sums of d_mind over blocks of LEARN_CHUNK entries (the host samples the next
 // candidates from these: block by cumulative sum, then the position inside the block)
 __global__ __launch_bounds__(256) void learn_min_update_kernel(float* __restrict__ mind, const float* __restrict__ dist, int64_t total,
-                                                               double* __restrict__ block_sums) {
+                                                               double* __restrict__ block_sums, const int* __restrict__ slot) {
   __shared__ double sh[256];
+  if (slot != nullptr) dist += (int64_t)slot[0] * total;     // (the device-side seeding loop: the winner's slot is decided on the device)
   const int64_t b0 = (int64_t)blockIdx.x * LEARN_CHUNK;
   double t = 0.0;
   for (int i = threadIdx.x; i < LEARN_CHUNK; i += 256) {
@@ -447,10 +448,75 @@ __global__ __launch_bounds__(256) void learn_min_update_kernel(float* __restrict
   if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
 }
 
-int launch_min_update(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total, double* d_block_sums) {
+int launch_min_update(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total, double* d_block_sums, const int* d_slot) {
   if (total <= 0) return PVS_OK;
   const int64_t nblk = (total + LEARN_CHUNK - 1) / LEARN_CHUNK;
-  hipLaunchKernelGGL(learn_min_update_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_mind, d_dist, total, d_block_sums);
+  hipLaunchKernelGGL(learn_min_update_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_mind, d_dist, total, d_block_sums, d_slot);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+// ---- greedy k-means++ without host round trips (pvs_kmeanspp_run_dev): the two decisions of a step on the device
+// targets r_j = u_j * pot and, for each, the 4096-entry block it falls into: searchsorted(cumsum(block_sums), r_j) with the
+// running fp64 sum in block order -- the numbers pvsim/learn.py:_draw_candidates forms on the host
+__global__ __launch_bounds__(64) void learn_seed_targets_kernel(const double* __restrict__ block_sums, int64_t nblk, const double* __restrict__ pot,
+                                                                const double* __restrict__ u, int trials, int64_t* __restrict__ blk,
+                                                                double* __restrict__ base, double* __restrict__ target) {
+  const int j = threadIdx.x;
+  if (j >= trials) return;
+  const double r = u[j] * pot[0];
+  double cum = 0.0, before = 0.0;
+  int64_t b = nblk - 1;
+  for (int64_t i = 0; i < nblk; ++i) {
+    before = cum;
+    cum += block_sums[i];
+    if (cum >= r) { b = i; break; }
+  }
+  blk[j] = b;
+  base[j] = b > 0 ? before : 0.0;
+  target[j] = r;
+}
+// the candidate with the smallest potential (the first of equals, as np.argmin): its slot for the running-minimum update,
+// its descriptor index as centre c, its potential as the next step's pot
+__global__ void learn_seed_choose_kernel(const double* __restrict__ pots, int trials, const int64_t* __restrict__ idx, double* __restrict__ pot,
+                                         int* __restrict__ slot, int64_t* __restrict__ indices, int c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int best = 0;
+  for (int j = 1; j < trials; ++j)
+    if (pots[j] < pots[best]) best = j;
+  slot[0] = best;
+  pot[0] = pots[best];
+  indices[c] = idx[best];
+}
+__global__ void learn_copy_row_kernel(const float* __restrict__ X, int D, const int64_t* __restrict__ indices, int c, float* __restrict__ cand) {
+  const int64_t row = indices[c];
+  for (int d = threadIdx.x; d < D; d += blockDim.x) cand[d] = X[row * D + d];
+}
+
+int launch_kmeanspp_run(pvs_ctx* ctx, const float* x, int64_t total, int D, int n_clusters, int trials, const double* d_uniform,
+                        float* d_mind, float* d_dist, float* d_cand, double* d_block_sums, char* d_small, int64_t* d_indices) {
+  // d_small: pots[8] | pot | blk[8] | base[8] | target[8] | idx[8] | slot
+  double* d_pots = reinterpret_cast<double*>(d_small);
+  double* d_pot = d_pots + 8;
+  int64_t* d_blk = reinterpret_cast<int64_t*>(d_pot + 1);
+  double* d_base = reinterpret_cast<double*>(d_blk + 8);
+  double* d_tgt = d_base + 8;
+  int64_t* d_idx = reinterpret_cast<int64_t*>(d_tgt + 8);
+  int* d_slot = reinterpret_cast<int*>(d_idx + 8);
+  const int64_t nblk = (total + LEARN_CHUNK - 1) / LEARN_CHUNK;
+  // first centre: its distances are the running minima
+  hipLaunchKernelGGL(learn_copy_row_kernel, dim3(1), dim3(64), 0, ctx->stream, x, D, d_indices, 0, d_cand);
+  PVS_TRY(launch_seed_distances(ctx, x, total, D, d_cand, 1, nullptr, d_dist, d_pots));
+  PVS_HIP(hipMemcpyAsync(d_pot, d_pots, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  PVS_TRY(launch_min_update(ctx, d_mind, d_dist, total, d_block_sums, nullptr));
+  for (int c = 1; c < n_clusters; ++c) {
+    hipLaunchKernelGGL(learn_seed_targets_kernel, dim3(1), dim3(64), 0, ctx->stream, d_block_sums, nblk, d_pot,
+                       d_uniform + (size_t)(c - 1) * trials, trials, d_blk, d_base, d_tgt);
+    PVS_TRY(launch_seed_pick(ctx, x, total, D, d_mind, d_blk, d_base, d_tgt, trials, d_idx, d_cand));
+    PVS_TRY(launch_seed_distances(ctx, x, total, D, d_cand, trials, d_mind, d_dist, d_pots));
+    hipLaunchKernelGGL(learn_seed_choose_kernel, dim3(1), dim3(1), 0, ctx->stream, d_pots, trials, d_idx, d_pot, d_slot, d_indices, c);
+    PVS_TRY(launch_min_update(ctx, d_mind, d_dist, total, d_block_sums, d_slot));
+  }
   PVS_HIP(hipGetLastError());
   return PVS_OK;
 }

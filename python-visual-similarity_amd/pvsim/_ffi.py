@@ -95,6 +95,7 @@ SIGNATURES = {
     "pvs_seed_distances_dev": [_vp, _vp, _int, _i64, _vp, _int, _vp, _vp, _vp, _int],
     "pvs_seed_pick_dev": [_vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _int, _vp, _vp],
     "pvs_min_update_dev": [_vp, _vp, _vp, _i64, _vp],
+    "pvs_kmeanspp_run_dev": [_vp, _vp, _int, _i64, _int, _int, _vp, _vp],
     "pvs_fused_profile": [_vp, _int, _vp],
     "pvs_timers_enable": [_vp, _int],
     "pvs_timers_reset": [_vp],

@@ -426,6 +426,18 @@ class Context:
         check(_ffi.lib().pvs_min_update_dev(self.handle, ptr(d_mind), ptr(d_dist), total_desc, ptr(bs)))
         return bs
 
+    def kmeanspp_run_dev(self, d_x, D, total_desc, n_clusters, trials, uniform, first_index):
+        """pvs_kmeanspp_run_dev: the greedy k-means++ run on the device (trials <= 8) -> indices (n_clusters,) int64."""
+        u = np.ascontiguousarray(uniform, dtype=np.float64).reshape(-1)
+        if u.size < max(n_clusters - 1, 0) * trials:
+            raise ValueError("need (n_clusters - 1) x trials uniform numbers")
+        idx = np.full(n_clusters, -1, dtype=np.int64)
+        idx[0] = first_index
+        if u.size == 0:
+            u = np.zeros(1)
+        check(_ffi.lib().pvs_kmeanspp_run_dev(self.handle, ptr(d_x), D, total_desc, n_clusters, trials, ptr(u), ptr(idx)))
+        return idx
+
     def fused_profile(self, enable=True, raw=False):
         """pvs_fused_profile: (re)start or stop the stamped diagnostic builds of the VLAD encode kernels -> the 16 counters so far
         (fused path: the names below; two-kernel path with raw=True: the prefilter's phase cycles, see tests/tools/assign_profile.py)."""

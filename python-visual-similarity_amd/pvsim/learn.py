@@ -138,15 +138,23 @@ def _draw_candidates(rows: DeviceRows, mind, block_sums: np.ndarray, r: np.ndarr
     return rows.ctx.seed_pick_dev(rows.ptr, rows.D, rows.n, mind.ptr, blocks, base, r, d_cand.ptr)
 
 
-def kmeans_plusplus(rows: DeviceRows, n_clusters: int, random_state=None, n_local_trials=None):
+def kmeans_plusplus(rows: DeviceRows, n_clusters: int, random_state=None, n_local_trials=None, stepwise=False):
     """Greedy k-means++ (sklearn/cluster/_kmeans.py:_kmeans_plusplus): first centre uniform, every further centre the
     best of 2 + log(K) candidates drawn with probability proportional to the squared distance to the nearest chosen
-    centre.  Draws, distances and potentials are device passes.  -> (centers (K, D) f32, indices (K,))"""
+    centre.  Draws, distances and potentials are device passes.  With up to 8 local trials (K < 404) the whole run is ONE
+    call without a host round trip per step (pvs_kmeanspp_run_dev: the random numbers of all steps go to the device up front,
+    targets = u * potential are formed there); `stepwise=True` takes the entry points one step at a time -- the same random
+    stream, the same arithmetic, the same indices.  -> (centers (K, D) f32, indices (K,))"""
     ctx, n, D = rows.ctx, rows.n, rows.D
     if n_clusters > n:
         raise ValueError(f"n_samples={n} should be >= n_clusters={n_clusters}.")
     rng = _rng(random_state)
     trials = n_local_trials or 2 + int(math.log(n_clusters))
+    if trials <= 8 and not stepwise:
+        first = rng.randint(n)
+        u = rng.uniform(size=(max(n_clusters - 1, 0), trials))      # row c-1: the draws of step c, as successive calls would give
+        indices = ctx.kmeanspp_run_dev(rows.ptr, D, n, n_clusters, trials, u, first)
+        return rows.rows(indices), indices
     indices = np.full(n_clusters, -1, dtype=np.int64)
     mind = ctx.buffer(n * 4).fill_bytes(_BIG_F32_BYTE)
     dist = ctx.buffer(min(trials, 8) * n * 4)

@@ -587,6 +587,11 @@ def test_learn_seeding_and_label_sums(gpu_ctx):
     c1, i1 = learn.kmeans_plusplus(rows, 16, random_state=3)
     c2, i2 = learn.kmeans_plusplus(rows, 16, random_state=3)
     assert np.array_equal(i1, i2) and np.array_equal(c1, c2) and len(set(i1.tolist())) == 16
+    # the run without host round trips (one call) and the stepwise entry points: the same random stream -> the same centres
+    for K_, rs in ((16, 3), (5, 11), (40, 7)):
+        _, ia = learn.kmeans_plusplus(rows, K_, random_state=rs)
+        _, ib = learn.kmeans_plusplus(rows, K_, random_state=rs, stepwise=True)
+        assert np.array_equal(ia, ib), (K_, rs, ia, ib)
     assert np.array_equal(c1, x[i1])
     # seeded k-means++ start + Lloyd reaches an inertia close to the reference's fit from its own start
     m = learn.fit_kmeans(rows, 16, random_state=3)

@@ -32,7 +32,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/pvsim.h but not exported"
     assert sorted(_ffi.SIGNATURES) == syms            # the ctypes table binds exactly the header
-    assert _ffi.lib().pvs_version() == 102
+    assert _ffi.lib().pvs_version() == 103
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
