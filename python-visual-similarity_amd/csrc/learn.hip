@@ -282,12 +282,16 @@ __global__ __launch_bounds__(256) void learn_seed_kernel(const float* __restrict
                                                          int nc, const float* __restrict__ mind, float* __restrict__ dist,
                                                          double* __restrict__ block_pot /*[SEED_MAX][nblk]*/) {
   extern __shared__ float sc[];  // [nc][D] candidates, then [32][SEED_MAX] row results
-  float* res = sc + nc * D;
+  float* res = sc + ((nc * D + 1) & ~1);     // 8-B aligned: it holds doubles at the end
   for (int i = threadIdx.x; i < nc * D; i += 256) sc[i] = cand[i];
   __syncthreads();
   const int l8 = threadIdx.x & 7, grp = threadIdx.x >> 3;   // 32 descriptors per round
   const bool vec = (D % 4 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0);
-  double pot = 0.0;  // thread c < SEED_MAX: this block's potential for candidate c, rows in order
+  // every 8-lane group keeps the fp64 potentials of ITS rows (one row per round) in registers: no barrier and no serial sum
+  // per round (the loop was bound by them: 156 -> see DESIGN 6b); the 32 group sums are added in group order at the end
+  double gp[SEED_MAX];
+#pragma unroll
+  for (int c = 0; c < SEED_MAX; ++c) gp[c] = 0.0;
   for (int round = 0; round < SEED_ROWS / 32; ++round) {
     const int64_t r0 = (int64_t)blockIdx.x * SEED_ROWS + round * 32;
     if (r0 >= total) break;
@@ -327,20 +331,27 @@ __global__ __launch_bounds__(256) void learn_seed_kernel(const float* __restrict
       s[c] += __shfl_xor(s[c], 2, 64);
       s[c] += __shfl_xor(s[c], 4, 64);
     }
-    if (l8 == 0) {
-      const float md = (row < total && mind != nullptr) ? mind[row] : INFINITY;
+    if (l8 == 0 && row < total) {
+      const float md = mind != nullptr ? mind[row] : INFINITY;
 #pragma unroll
-      for (int c = 0; c < SEED_MAX; ++c) {
-        if (c < nc && row < total) dist[(int64_t)c * total + row] = s[c];
-        res[grp * SEED_MAX + c] = (c < nc && row < total) ? fminf(md, s[c]) : 0.f;
-      }
+      for (int c = 0; c < SEED_MAX; ++c)
+        if (c < nc) {
+          dist[(int64_t)c * total + row] = s[c];
+          gp[c] += (double)fminf(md, s[c]);
+        }
     }
-    __syncthreads();
-    if (threadIdx.x < SEED_MAX)
-      for (int jj = 0; jj < 32; ++jj) pot += (double)res[jj * SEED_MAX + threadIdx.x];
-    __syncthreads();
   }
-  if (threadIdx.x < SEED_MAX) block_pot[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = pot;
+  double* resd = reinterpret_cast<double*>(res);     // [32 groups][SEED_MAX]
+  if (l8 == 0) {
+#pragma unroll
+    for (int c = 0; c < SEED_MAX; ++c) resd[grp * SEED_MAX + c] = gp[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < SEED_MAX) {
+    double pot = 0.0;
+    for (int jj = 0; jj < 32; ++jj) pot += resd[jj * SEED_MAX + threadIdx.x];
+    block_pot[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = pot;
+  }
 }
 
 // block c: d_pot[c] = sum of block_pot[c][0..nblk)  (strided partial sums, fixed tree)
@@ -362,7 +373,7 @@ int launch_seed_distances(pvs_ctx* ctx, const float* x, int64_t total, int D, co
                           const float* d_mind, float* d_dist, double* d_pot) {
   if (n_cand < 1 || n_cand > SEED_MAX) PVS_FAIL(PVS_ERR_INVALID, "1..%d seeding candidates per call (got %d)", SEED_MAX, n_cand);
   if (total <= 0) PVS_FAIL(PVS_ERR_INVALID, "seeding needs at least one descriptor");
-  const size_t lds = ((size_t)n_cand * D + 64 * SEED_MAX) * 4;
+  const size_t lds = ((size_t)n_cand * D + 2 + 64 * SEED_MAX) * 4;
   if (lds > 64 * 1024) PVS_FAIL(PVS_ERR_UNSUPPORTED, "descriptor dimension %d too large for the seeding kernel", D);
   const int64_t nblk = (total + SEED_ROWS - 1) / SEED_ROWS;
   double* bp = nullptr;
