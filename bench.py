@@ -273,6 +273,7 @@ def side_workload(args):
         out.update({"metric": "descriptors/sec through k-means++ seeding + 10 Lloyd iterations + 5 EM iterations + PCA fit (K=256, D=128)",
                     "value": round(total / dt, 1), "unit": "descriptors/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "f32 (k-means), f64 (EM, PCA)",
                     "scaling": "strong", "stages_ms_per_step": st, "phases_s": {k: round(v, 4) for k, v in res.items()},
+                    "phase_samples_s": {k_: [round(t_, 4) for t_ in v_[-max(args.steps, 1):]] for k_, v_ in samples.items()},
                     "config": {"workload": f"{total} RootSIFT descriptors x {DIM}, K = {K_CLUSTERS}"}})
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(REPO, "oracle"))

@@ -67,8 +67,13 @@ class DeviceBuffer:
 
     def __init__(self, ctx: "Context", nbytes: int):
         self._ctx, self.nbytes, self.ptr = ctx, int(nbytes), 0
+        self._cap = max(int(nbytes), 16)
+        hit = ctx._take_cached(self._cap)
+        if hit is not None:                      # a block this context released earlier: no hipMalloc / hipFree on the hot path
+            self.ptr, self._cap = hit
+            return
         p = C.c_void_p()
-        check(_ffi.lib().pvs_malloc(ctx.handle, max(int(nbytes), 16), C.byref(p)))
+        check(_ffi.lib().pvs_malloc(ctx.handle, self._cap, C.byref(p)))
         self.ptr = int(p.value)
 
     @classmethod
@@ -98,7 +103,8 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr and not getattr(self, "_borrowed", False) and self._ctx.handle is not None:
-            _ffi.lib().pvs_free(self._ctx.handle, C.c_void_p(self.ptr))
+            if not self._ctx._give_cached(self.ptr, getattr(self, "_cap", self.nbytes)):
+                _ffi.lib().pvs_free(self._ctx.handle, C.c_void_p(self.ptr))
         self.ptr = 0
 
     def __del__(self):
@@ -118,10 +124,37 @@ class Context:
         check(_ffi.lib().pvs_init(int(device), C.c_void_p(stream), C.byref(h)))
         self.handle = h
         self.device = int(device)
+        self._cache = []          # released DeviceBuffers kept for reuse: [(capacity, ptr)], bounded (training loops allocate the same sizes over and over; hipFree synchronises the device)
+
+    _CACHE_BLOCKS, _CACHE_BYTES = 24, 2 << 30
+
+    def _take_cached(self, nbytes):
+        best = None
+        for i, (cap, p) in enumerate(self._cache):
+            if nbytes <= cap <= 2 * nbytes + 4096 and (best is None or cap < self._cache[best][0]):
+                best = i
+        if best is None:
+            return None
+        cap, p = self._cache.pop(best)
+        return p, cap
+
+    def _give_cached(self, p, cap):
+        if len(self._cache) >= self._CACHE_BLOCKS or cap + sum(c for c, _ in self._cache) > self._CACHE_BYTES:
+            return False
+        self._cache.append((int(cap), int(p)))
+        return True
+
+    def trim(self):
+        """Return the cached device blocks to the driver."""
+        while self._cache:
+            _, p = self._cache.pop()
+            if self.handle is not None:
+                _ffi.lib().pvs_free(self.handle, C.c_void_p(p))
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
         if self.handle is not None:
+            self.trim()
             _ffi.lib().pvs_destroy(self.handle)
             self.handle = None
 
