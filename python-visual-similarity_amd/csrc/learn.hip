@@ -273,7 +273,7 @@ int launch_gram(pvs_ctx* ctx, const float* x, int64_t total, int D, double* d_ou
 // d_mind null = no centre chosen yet (potential = plain sum of distances).
 constexpr int SEED_MAX = 8;
 
-constexpr int SEED_ROWS = 1024;  // descriptors per block (32 rounds of 32)
+constexpr int SEED_ROWS = 256;   // descriptors per block (8 rounds of 32): at 1024 a pass over 5e5 rows was 512 blocks, two per CU, each a chain of 32 dependent loads (1.8 TB/s)
 
 // Eight lanes share a descriptor (each takes dims 4 l, 4 l + 32, ... as float4: a row's lanes read 128 contiguous bytes per
 // step), every lane keeps its partial |x - cand_j|^2 for all candidates in registers, and one 3-step butterfly per candidate
