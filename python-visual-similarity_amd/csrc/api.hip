@@ -44,8 +44,8 @@ static int drain_timers(pvs_ctx* ctx) {
       ctx->t_total[r.slot] += ms;
       ctx->t_count[r.slot] += 1;
     }
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    ctx->event_pool.push_back(r.a);
+    ctx->event_pool.push_back(r.b);
   }
   ctx->pending.clear();
   return PVS_OK;
@@ -149,6 +149,8 @@ PVS_EXPORT int pvs_destroy(pvs_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   drain_timers(ctx);
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  ctx->event_pool.clear();
   for (int i = 0; i < pvs_ctx::NWS; ++i)
     if (ctx->ws[i]) hipFree(ctx->ws[i]);
   for (auto& p : ctx->gemm_plan)

@@ -80,6 +80,7 @@ struct pvs_ctx {
   // timers
   bool timers_on = false;
   std::vector<pvs::TimerRec> pending;
+  std::vector<hipEvent_t> event_pool;    // recycled timer events (destroyed with the context)
   double t_total[PVS_TIMER_SLOTS] = {0};
   int64_t t_count[PVS_TIMER_SLOTS] = {0};
 };
@@ -138,11 +139,22 @@ struct ScopedTimer {
   pvs_ctx* ctx;
   int slot;
   hipEvent_t a = nullptr, b = nullptr;
+  hipEvent_t take_event() {
+    if (!ctx->event_pool.empty()) {
+      hipEvent_t e = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+  }
   ScopedTimer(pvs_ctx* c, int s) : ctx(c), slot(s) {
     if (ctx->timers_on) {
       // a long-running caller that never reads the timers must not pile up events: fold in the finished ones (in order,
       // non-blocking) once a few hundred are pending
-      if (ctx->pending.size() >= 512) {
+      // (events are recycled through ctx->event_pool: creating and destroying a pair per launch cost ~0.15 ms, and folding
+      // 512 pairs at once was a 75-ms stall inside the timed region of a loop with many launches)
+      if (ctx->pending.size() >= 128) {
         size_t done = 0;
         while (done < ctx->pending.size() && hipEventQuery(ctx->pending[done].b) == hipSuccess) {
           float ms = 0.f;
@@ -150,15 +162,16 @@ struct ScopedTimer {
             ctx->t_total[ctx->pending[done].slot] += ms;
             ctx->t_count[ctx->pending[done].slot] += 1;
           }
-          (void)hipEventDestroy(ctx->pending[done].a);
-          (void)hipEventDestroy(ctx->pending[done].b);
+          ctx->event_pool.push_back(ctx->pending[done].a);
+          ctx->event_pool.push_back(ctx->pending[done].b);
           ++done;
         }
         ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + done);
       }
-      (void)hipEventCreate(&a);
-      (void)hipEventCreate(&b);
-      (void)hipEventRecord(a, ctx->stream);
+      a = take_event();
+      b = take_event();
+      if (a && b) (void)hipEventRecord(a, ctx->stream);
+      else a = nullptr;
     }
   }
   ~ScopedTimer() {
