@@ -233,7 +233,7 @@ int launch_seed_distances(pvs_ctx* ctx, const float* x, int64_t total, int D, co
                           const float* d_mind, float* d_dist, double* d_pot);
 int launch_seed_pick(pvs_ctx* ctx, const float* x, int64_t total, int D, const float* d_mind, const int64_t* d_blk,
                      const double* d_base, const double* d_target, int n_cand, int64_t* d_idx, float* d_cand);
-int launch_min_update(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total, double* d_block_sums, const int* d_slot = nullptr);
+int launch_min_update(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total, double* d_block_sums);
 int launch_kmeanspp_run(pvs_ctx* ctx, const float* x, int64_t total, int D, int n_clusters, int trials, const double* d_uniform,
                         float* d_mind, float* d_dist, float* d_cand, double* d_block_sums, char* d_small, int64_t* d_indices);
 

@@ -387,15 +387,38 @@ int launch_seed_distances(pvs_ctx* ctx, const float* x, int64_t total, int D, co
 // Candidate draw of one seeding step, on the device: candidate c falls into block blk[c] (chosen by the host from the
 // per-block sums) at the first position whose running fp64 sum of d_mind, started at base[c], reaches target[c]
 // (= searchsorted(cumsum(mind), r), sklearn/cluster/_kmeans.py:_kmeans_plusplus); its row is copied to cand[c].
+// With `u` (the device-side run, pvs_kmeanspp_run_dev) the block of the draw is found here as well: target = u[c] * pot and
+// searchsorted(cumsum(block_sums), target) with the running fp64 sum in block order -- the numbers pvsim/learn.py:_draw_candidates
+// forms on the host for the stepwise call.
 __global__ __launch_bounds__(64) void learn_pick_kernel(const float* __restrict__ X, int64_t total, int D, const float* __restrict__ mind,
                                                         const int64_t* __restrict__ blk, const double* __restrict__ base,
                                                         const double* __restrict__ target, int64_t* __restrict__ out_idx,
-                                                        float* __restrict__ cand) {
+                                                        float* __restrict__ cand, const double* __restrict__ u = nullptr,
+                                                        const double* __restrict__ pot = nullptr,
+                                                        const double* __restrict__ block_sums = nullptr, int64_t nblk = 0) {
   __shared__ float vals[LEARN_CHUNK];
   __shared__ double part[64];
   __shared__ int64_t s_idx;
+  __shared__ int64_t s_blk;
+  __shared__ double s_base, s_tgt;
   const int c = blockIdx.x, t = threadIdx.x;
-  const int64_t lo = blk[c] * LEARN_CHUNK;
+  if (t == 0) {
+    if (u != nullptr) {
+      const double r = u[c] * pot[0];
+      double cum = 0.0, before = 0.0;
+      int64_t b = nblk - 1;
+      for (int64_t i = 0; i < nblk; ++i) {
+        before = cum;
+        cum += block_sums[i];
+        if (cum >= r) { b = i; break; }
+      }
+      s_blk = b; s_base = b > 0 ? before : 0.0; s_tgt = r;
+    } else {
+      s_blk = blk[c]; s_base = base[c]; s_tgt = target[c];
+    }
+  }
+  __syncthreads();
+  const int64_t lo = s_blk * LEARN_CHUNK;
   const int cnt = (int)min((int64_t)LEARN_CHUNK, total - lo);
   for (int i = t; i < LEARN_CHUNK; i += 64) vals[i] = i < cnt ? mind[lo + i] : 0.f;   // coalesced; zeros past the end
   __syncthreads();
@@ -406,16 +429,16 @@ __global__ __launch_bounds__(64) void learn_pick_kernel(const float* __restrict_
   part[t] = p;
   __syncthreads();
   if (t == 0) {
-    double run = base[c];
+    double run = s_base;
     int sub = 63;
-    for (int u = 0; u < 64; ++u) {
-      if (run + part[u] >= target[c]) { sub = u; break; }
-      run += part[u];
+    for (int q = 0; q < 64; ++q) {
+      if (run + part[q] >= s_tgt) { sub = q; break; }
+      run += part[q];
     }
     int pos = min(sub * RUN + RUN - 1, cnt - 1);
     for (int i = 0; i < RUN; ++i) {
       run += (double)vals[sub * RUN + i];
-      if (run >= target[c]) { pos = sub * RUN + i; break; }
+      if (run >= s_tgt) { pos = sub * RUN + i; break; }
     }
     pos = min(pos, cnt - 1);
     s_idx = lo + pos;
@@ -436,10 +459,38 @@ int launch_seed_pick(pvs_ctx* ctx, const float* x, int64_t total, int D, const f
 
 // d_mind = min(d_mind, d_dist) and the fp64 sums of d_mind over blocks of LEARN_CHUNK entries (the host samples the next
 // candidates from these: block by cumulative sum, then the position inside the block)
+// With `block_pot` (the device-side run) every block first forms the candidates' potentials from the distance pass's block sums --
+// the reduction of learn_seed_reduce_kernel, addition for addition -- and takes the first minimum (np.argmin); block 0 records
+// the winner's descriptor index and potential.
 __global__ __launch_bounds__(256) void learn_min_update_kernel(float* __restrict__ mind, const float* __restrict__ dist, int64_t total,
-                                                               double* __restrict__ block_sums, const int* __restrict__ slot) {
+                                                               double* __restrict__ block_sums, const double* __restrict__ block_pot = nullptr,
+                                                               int64_t nblk_seed = 0, int trials = 0, const int64_t* __restrict__ idx = nullptr,
+                                                               double* __restrict__ pot = nullptr, int64_t* __restrict__ indices = nullptr, int c = 0) {
   __shared__ double sh[256];
-  if (slot != nullptr) dist += (int64_t)slot[0] * total;     // (the device-side seeding loop: the winner's slot is decided on the device)
+  __shared__ double s_pots[8];
+  if (block_pot != nullptr) {
+    for (int j = 0; j < trials; ++j) {
+      const double* v = block_pot + (int64_t)j * nblk_seed;
+      double t = 0.0;
+      for (int64_t i = threadIdx.x; i < nblk_seed; i += 256) t += v[i];
+      sh[threadIdx.x] = t;
+      __syncthreads();
+      for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) s_pots[j] = sh[0];
+      __syncthreads();
+    }
+    int best = 0;
+    for (int j = 1; j < trials; ++j)
+      if (s_pots[j] < s_pots[best]) best = j;
+    dist += (int64_t)best * total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      pot[0] = s_pots[best];
+      indices[c] = idx[best];
+    }
+  }
   const int64_t b0 = (int64_t)blockIdx.x * LEARN_CHUNK;
   double t = 0.0;
   for (int i = threadIdx.x; i < LEARN_CHUNK; i += 256) {
@@ -459,46 +510,18 @@ __global__ __launch_bounds__(256) void learn_min_update_kernel(float* __restrict
   if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
 }
 
-int launch_min_update(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total, double* d_block_sums, const int* d_slot) {
+int launch_min_update(pvs_ctx* ctx, float* d_mind, const float* d_dist, int64_t total, double* d_block_sums) {
   if (total <= 0) return PVS_OK;
   const int64_t nblk = (total + LEARN_CHUNK - 1) / LEARN_CHUNK;
-  hipLaunchKernelGGL(learn_min_update_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_mind, d_dist, total, d_block_sums, d_slot);
+  hipLaunchKernelGGL(learn_min_update_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_mind, d_dist, total, d_block_sums,
+                     static_cast<const double*>(nullptr), (int64_t)0, 0, static_cast<const int64_t*>(nullptr), static_cast<double*>(nullptr),
+                     static_cast<int64_t*>(nullptr), 0);
   PVS_HIP(hipGetLastError());
   return PVS_OK;
 }
 
-// ---- greedy k-means++ without host round trips (pvs_kmeanspp_run_dev): the two decisions of a step on the device
-// targets r_j = u_j * pot and, for each, the 4096-entry block it falls into: searchsorted(cumsum(block_sums), r_j) with the
-// running fp64 sum in block order -- the numbers pvsim/learn.py:_draw_candidates forms on the host
-__global__ __launch_bounds__(64) void learn_seed_targets_kernel(const double* __restrict__ block_sums, int64_t nblk, const double* __restrict__ pot,
-                                                                const double* __restrict__ u, int trials, int64_t* __restrict__ blk,
-                                                                double* __restrict__ base, double* __restrict__ target) {
-  const int j = threadIdx.x;
-  if (j >= trials) return;
-  const double r = u[j] * pot[0];
-  double cum = 0.0, before = 0.0;
-  int64_t b = nblk - 1;
-  for (int64_t i = 0; i < nblk; ++i) {
-    before = cum;
-    cum += block_sums[i];
-    if (cum >= r) { b = i; break; }
-  }
-  blk[j] = b;
-  base[j] = b > 0 ? before : 0.0;
-  target[j] = r;
-}
-// the candidate with the smallest potential (the first of equals, as np.argmin): its slot for the running-minimum update,
-// its descriptor index as centre c, its potential as the next step's pot
-__global__ void learn_seed_choose_kernel(const double* __restrict__ pots, int trials, const int64_t* __restrict__ idx, double* __restrict__ pot,
-                                         int* __restrict__ slot, int64_t* __restrict__ indices, int c) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int best = 0;
-  for (int j = 1; j < trials; ++j)
-    if (pots[j] < pots[best]) best = j;
-  slot[0] = best;
-  pot[0] = pots[best];
-  indices[c] = idx[best];
-}
+// ---- greedy k-means++ without host round trips (pvs_kmeanspp_run_dev): three launches per step -- draw (learn_pick_kernel finds the
+// block of each target itself), distances (learn_seed_kernel), choice + running-minimum update (learn_min_update_kernel)
 __global__ void learn_copy_row_kernel(const float* __restrict__ X, int D, const int64_t* __restrict__ indices, int c, float* __restrict__ cand) {
   const int64_t row = indices[c];
   for (int d = threadIdx.x; d < D; d += blockDim.x) cand[d] = X[row * D + d];
@@ -506,27 +529,27 @@ __global__ void learn_copy_row_kernel(const float* __restrict__ X, int D, const 
 
 int launch_kmeanspp_run(pvs_ctx* ctx, const float* x, int64_t total, int D, int n_clusters, int trials, const double* d_uniform,
                         float* d_mind, float* d_dist, float* d_cand, double* d_block_sums, char* d_small, int64_t* d_indices) {
-  // d_small: pots[8] | pot | blk[8] | base[8] | target[8] | idx[8] | slot
+  // d_small: pots[8] | pot | idx[8]
   double* d_pots = reinterpret_cast<double*>(d_small);
   double* d_pot = d_pots + 8;
-  int64_t* d_blk = reinterpret_cast<int64_t*>(d_pot + 1);
-  double* d_base = reinterpret_cast<double*>(d_blk + 8);
-  double* d_tgt = d_base + 8;
-  int64_t* d_idx = reinterpret_cast<int64_t*>(d_tgt + 8);
-  int* d_slot = reinterpret_cast<int*>(d_idx + 8);
-  const int64_t nblk = (total + LEARN_CHUNK - 1) / LEARN_CHUNK;
+  int64_t* d_idx = reinterpret_cast<int64_t*>(d_pot + 1);
+  const int64_t nblk = (total + LEARN_CHUNK - 1) / LEARN_CHUNK, nblk_seed = (total + SEED_ROWS - 1) / SEED_ROWS;
+  const size_t lds = ((size_t)trials * D + 2 + 64 * SEED_MAX) * 4;
+  if (lds > 64 * 1024) PVS_FAIL(PVS_ERR_UNSUPPORTED, "descriptor dimension %d too large for the seeding kernel", D);
+  double* bp = nullptr;
+  PVS_TRY(ws_reserve(ctx, 1, (size_t)nblk_seed * SEED_MAX * 8, reinterpret_cast<void**>(&bp)));
   // first centre: its distances are the running minima
   hipLaunchKernelGGL(learn_copy_row_kernel, dim3(1), dim3(64), 0, ctx->stream, x, D, d_indices, 0, d_cand);
   PVS_TRY(launch_seed_distances(ctx, x, total, D, d_cand, 1, nullptr, d_dist, d_pots));
   PVS_HIP(hipMemcpyAsync(d_pot, d_pots, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  PVS_TRY(launch_min_update(ctx, d_mind, d_dist, total, d_block_sums, nullptr));
+  PVS_TRY(launch_min_update(ctx, d_mind, d_dist, total, d_block_sums));
   for (int c = 1; c < n_clusters; ++c) {
-    hipLaunchKernelGGL(learn_seed_targets_kernel, dim3(1), dim3(64), 0, ctx->stream, d_block_sums, nblk, d_pot,
-                       d_uniform + (size_t)(c - 1) * trials, trials, d_blk, d_base, d_tgt);
-    PVS_TRY(launch_seed_pick(ctx, x, total, D, d_mind, d_blk, d_base, d_tgt, trials, d_idx, d_cand));
-    PVS_TRY(launch_seed_distances(ctx, x, total, D, d_cand, trials, d_mind, d_dist, d_pots));
-    hipLaunchKernelGGL(learn_seed_choose_kernel, dim3(1), dim3(1), 0, ctx->stream, d_pots, trials, d_idx, d_pot, d_slot, d_indices, c);
-    PVS_TRY(launch_min_update(ctx, d_mind, d_dist, total, d_block_sums, d_slot));
+    hipLaunchKernelGGL(learn_pick_kernel, dim3((unsigned)trials), dim3(64), 0, ctx->stream, x, total, D, d_mind, static_cast<const int64_t*>(nullptr),
+                       static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), d_idx, d_cand,
+                       d_uniform + (size_t)(c - 1) * trials, d_pot, d_block_sums, nblk);
+    hipLaunchKernelGGL(learn_seed_kernel, dim3((unsigned)nblk_seed), dim3(256), lds, ctx->stream, x, total, D, d_cand, trials, d_mind, d_dist, bp);
+    hipLaunchKernelGGL(learn_min_update_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_mind, d_dist, total, d_block_sums, bp,
+                       nblk_seed, trials, d_idx, d_pot, d_indices, c);
   }
   PVS_HIP(hipGetLastError());
   return PVS_OK;
