@@ -81,12 +81,25 @@ def test_vlad_shapes_vs_oracle(gpu_ctx, K, D):
     ref_labels = orc.kmeans_predict(packed, C)
     lab64, gap = orc.assignment_margin(packed, C)
     bad = labels != ref_labels
-    assert np.all(gap[bad] < 1e-4 * (1 + np.abs(packed[bad]).sum(1)))   # only near-ties may differ
-    ref = np.vstack([orc.vlad_normalise(orc.vlad_aggregate(x, labels[o:o + len(x)], C), 1, 2, 1e-9).reshape(-1)
-                     if len(x) else np.zeros(K * D, np.float32)
-                     for x, o in zip(imgs, offsets[:-1])])
-    np.testing.assert_allclose(v, ref, rtol=0, atol=2e-6)
-    assert not v[0].any()                                               # empty image -> zero row
+    # only near ties may differ: the fp64 gap of the two nearest centres must be below what a D-term fp32 evaluation of
+    # |c|^2 - 2 x.c resolves (worst case (D + 4) 2^-23 (|x||c| + |c|^2) on either side)
+    cmax = float(np.linalg.norm(C, axis=1).max())
+    lim = 2.0 * (D + 4) * 2.0 ** -23 * (np.linalg.norm(packed[bad].astype(np.float64), axis=1) * cmax + cmax * cmax)
+    assert np.all(gap[bad] < lim), (gap[bad] / lim).max()
+    assert bad.mean() < 2e-3
+    # values: every image whose labels all agree with the oracle's is compared with the oracle end to end (labels AND sums);
+    # an image holding a flipped near tie is compared with the oracle's aggregate of the device labels
+    n_full = 0
+    for i, (x, o) in enumerate(zip(imgs, offsets[:-1])):
+        if not len(x):
+            assert not v[i].any()                                       # empty image -> zero row
+            continue
+        same = not bad[o:o + len(x)].any()
+        lab = ref_labels[o:o + len(x)] if same else labels[o:o + len(x)]
+        ref = orc.vlad_normalise(orc.vlad_aggregate(x, lab, C), 1, 2, 1e-9).reshape(-1)
+        np.testing.assert_allclose(v[i], ref, rtol=0, atol=2e-6)
+        n_full += same
+    assert n_full >= len(imgs) - 3
 
 
 def test_labels_large_only_near_ties(gpu_ctx, tables):
