@@ -208,6 +208,18 @@ def _check_topk(gpu_ctx, q, db, k):
     ridx, rval = orc.topk(s, k)
     assert np.array_equal(idx, ridx)
     assert np.array_equal(val, rval)
+    # ... and against the oracle's own scores: the same index at every rank whose oracle score is separated from both
+    # neighbours by more than the two evaluations can differ (2e-6 each), the same value within that tolerance everywhere
+    so = orc.cosine_similarity(q, db).astype(np.float64)
+    order = np.argsort(-so, axis=1, kind="stable")[:, :min(k + 1, so.shape[1])]
+    sv = np.take_along_axis(so, order, axis=1)
+    kk = min(k, so.shape[1])
+    np.testing.assert_allclose(val[:, :kk], sv[:, :kk], rtol=0, atol=3e-6)
+    gap_prev = np.hstack([np.full((len(sv), 1), np.inf), sv[:, :-1] - sv[:, 1:]])[:, :kk]
+    gap_next = np.hstack([sv[:, :-1] - sv[:, 1:], np.full((len(sv), 1), np.inf)])[:, :kk]
+    clear = (gap_prev > 5e-6) & (gap_next > 5e-6)
+    assert np.array_equal(idx[:, :kk][clear], order[:, :kk][clear])
+    assert clear.mean() > 0.5
 
 
 @pytest.mark.parametrize("nq,N,k", [(5, 10, 3), (7, 8189, 5), (3, 8189, 100), (2, 20000, 1000), (4, 300, 300),
