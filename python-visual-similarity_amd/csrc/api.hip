@@ -51,9 +51,41 @@ static int drain_timers(pvs_ctx* ctx) {
   return PVS_OK;
 }
 
+// ---- device blocks of table objects: recycled through the context (see pvs_ctx::block_cache)
+static int table_alloc(pvs_ctx* ctx, void** dptr, size_t bytes) {
+  const size_t want = (std::max<size_t>(bytes, 16) + 255) / 256 * 256;
+  auto it = ctx->block_cache.lower_bound(want);
+  if (it != ctx->block_cache.end() && it->first <= 2 * want + 4096) {
+    *dptr = it->second;
+    ctx->block_size[*dptr] = it->first;
+    ctx->block_cache_bytes -= it->first;
+    ctx->block_cache.erase(it);
+    return PVS_OK;
+  }
+  PVS_HIP(hipMalloc(dptr, want));
+  ctx->block_size[*dptr] = want;
+  return PVS_OK;
+}
+static void table_free(pvs_ctx* ctx, void* p) {
+  if (!p) return;
+  if (ctx) {
+    auto it = ctx->block_size.find(p);
+    if (it != ctx->block_size.end()) {
+      const size_t cap = it->second;
+      ctx->block_size.erase(it);
+      if (ctx->block_cache.size() < 96 && ctx->block_cache_bytes + cap <= ((size_t)1 << 30)) {
+        ctx->block_cache.emplace(cap, p);
+        ctx->block_cache_bytes += cap;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+
 template <typename T>
 static int upload(pvs_ctx* ctx, T** dptr, const T* host, size_t count) {
-  PVS_HIP(hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(count, 1) * sizeof(T)));
+  PVS_TRY(table_alloc(ctx, reinterpret_cast<void**>(dptr), std::max<size_t>(count, 1) * sizeof(T)));
   PVS_HIP(hipMemcpyAsync(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
   return PVS_OK;
 }
@@ -151,6 +183,8 @@ PVS_EXPORT int pvs_destroy(pvs_ctx* ctx) {
   drain_timers(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   ctx->event_pool.clear();
+  for (auto& kv : ctx->block_cache) (void)hipFree(kv.second);
+  ctx->block_cache.clear();
   for (int i = 0; i < pvs_ctx::NWS; ++i)
     if (ctx->ws[i]) hipFree(ctx->ws[i]);
   for (auto& p : ctx->gemm_plan)
@@ -316,7 +350,7 @@ PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, 
         h16[o] = hi;
         h16[tab + o] = (_Float16)(v - (float)hi);   // v - hi is exact in fp32
       }
-    if (hipMalloc(&cb->d_c16, h16.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
+    if (table_alloc(ctx, &cb->d_c16, h16.size() * 2) != PVS_OK) st = PVS_ERR_OOM;
     else if (hipMemcpyAsync(cb->d_c16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
     if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;   // h16 goes out of scope
     // -|c|^2/2 as three exact fp16 pieces per cluster (the prefilter adds it on the matrix pipe, vlad.hip / vlad_fused.hip)
@@ -340,9 +374,9 @@ PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, 
         }
       }
       if (!(std::isfinite(amaxa) && amaxa > 0.f)) {       // degenerate table: no prefilter at all
-        hipFree(cb->d_c16);
+        table_free(ctx, cb->d_c16);
         cb->d_c16 = nullptr;
-      } else if (hipMalloc(&cb->d_cnk, pk.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
+      } else if (table_alloc(ctx, &cb->d_cnk, pk.size() * 2) != PVS_OK) st = PVS_ERR_OOM;
       else if (hipMemcpyAsync(cb->d_cnk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
       if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
     }
@@ -356,7 +390,7 @@ PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, 
           n16[(size_t)k * 128 + d] = hi;
           n16[(size_t)256 * 128 + (size_t)k * 128 + d] = (_Float16)(v - (float)hi);
         }
-      if (hipMalloc(&cb->d_c16n, n16.size() * 2) != hipSuccess) st = PVS_ERR_OOM;
+      if (table_alloc(ctx, &cb->d_c16n, n16.size() * 2) != PVS_OK) st = PVS_ERR_OOM;
       else if (hipMemcpyAsync(cb->d_c16n, n16.data(), n16.size() * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
       if (st == PVS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PVS_ERR_NO_DEVICE;
     }
@@ -373,12 +407,12 @@ PVS_EXPORT int pvs_codebook_create(pvs_ctx* ctx, const float* centroids, int K, 
 PVS_EXPORT int pvs_codebook_destroy(pvs_ctx* ctx, pvs_codebook* cb) {
   if (!cb) return PVS_OK;
   if (ctx) hipStreamSynchronize(ctx->stream);
-  if (cb->d_cent) hipFree(cb->d_cent);
-  if (cb->d_cpad) hipFree(cb->d_cpad);
-  if (cb->d_cnorm) hipFree(cb->d_cnorm);
-  if (cb->d_c16) hipFree(cb->d_c16);
-  if (cb->d_c16n) hipFree(cb->d_c16n);
-  if (cb->d_cnk) hipFree(cb->d_cnk);
+  table_free(ctx, cb->d_cent);
+  table_free(ctx, cb->d_cpad);
+  table_free(ctx, cb->d_cnorm);
+  table_free(ctx, cb->d_c16);
+  table_free(ctx, cb->d_c16n);
+  table_free(ctx, cb->d_cnk);
   delete cb;
   return PVS_OK;
 }
@@ -442,7 +476,7 @@ PVS_EXPORT int pvs_gmm_destroy(pvs_ctx* ctx, pvs_gmm* g) {
   if (!g) return PVS_OK;
   if (ctx) hipStreamSynchronize(ctx->stream);
   for (double* p : {g->d_w, g->d_mu, g->d_cov, g->d_prec, g->d_mup, g->d_const, g->d_inv_mu, g->d_inv_sg})
-    if (p) hipFree(p);
+    table_free(ctx, p);
   delete g;
   return PVS_OK;
 }
@@ -479,8 +513,8 @@ PVS_EXPORT int pvs_pca_create(pvs_ctx* ctx, const float* components, const float
 PVS_EXPORT int pvs_pca_destroy(pvs_ctx* ctx, pvs_pca* p) {
   if (!p) return PVS_OK;
   if (ctx) hipStreamSynchronize(ctx->stream);
-  if (p->d_comp) hipFree(p->d_comp);
-  if (p->d_off) hipFree(p->d_off);
+  table_free(ctx, p->d_comp);
+  table_free(ctx, p->d_off);
   delete p;
   return PVS_OK;
 }

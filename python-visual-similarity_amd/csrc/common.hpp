@@ -81,6 +81,11 @@ struct pvs_ctx {
   bool timers_on = false;
   std::vector<pvs::TimerRec> pending;
   std::vector<hipEvent_t> event_pool;    // recycled timer events (destroyed with the context)
+  // device blocks of destroyed table objects (codebooks, mixtures, projections), kept for the next one: a training loop creates
+  // and destroys a codebook per iteration, and a hipFree can stall the host for tens of milliseconds (measured: 74 ms)
+  std::multimap<size_t, void*> block_cache;      // capacity -> block
+  std::map<void*, size_t> block_size;            // live blocks handed out by table_alloc
+  size_t block_cache_bytes = 0;
   double t_total[PVS_TIMER_SLOTS] = {0};
   int64_t t_count[PVS_TIMER_SLOTS] = {0};
 };
