@@ -185,6 +185,7 @@ PVS_EXPORT int pvs_destroy(pvs_ctx* ctx) {
   ctx->event_pool.clear();
   for (auto& kv : ctx->block_cache) (void)hipFree(kv.second);
   ctx->block_cache.clear();
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (int i = 0; i < pvs_ctx::NWS; ++i)
     if (ctx->ws[i]) hipFree(ctx->ws[i]);
   for (auto& p : ctx->gemm_plan)
@@ -995,8 +996,27 @@ PVS_EXPORT int pvs_cosine_topk_f64(pvs_ctx* ctx, const double* Q, int64_t nq, co
 }
 
 // ================================================================================ vocabulary training
+// Through a pinned staging block of the context: a copy into pageable caller memory makes the driver pin the caller's pages on
+// every call (0.5 ms for 262 KB in the HIP trace of the training loop; the results come back once per iteration).
 static int stats_to_host(pvs_ctx* ctx, const double* d_stats, size_t n, double* h_out) {
-  PVS_HIP(hipMemcpyAsync(h_out, d_stats, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  const size_t bytes = n * sizeof(double);
+  if (bytes <= ((size_t)8 << 20)) {
+    if (ctx->h_stage_bytes < bytes) {
+      if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+      ctx->h_stage = nullptr;
+      ctx->h_stage_bytes = 0;
+      const size_t want = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
+      if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) == hipSuccess) ctx->h_stage_bytes = want;
+      else ctx->h_stage = nullptr;
+    }
+    if (ctx->h_stage) {
+      PVS_HIP(hipMemcpyAsync(ctx->h_stage, d_stats, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      PVS_HIP(hipStreamSynchronize(ctx->stream));
+      memcpy(h_out, ctx->h_stage, bytes);
+      return PVS_OK;
+    }
+  }
+  PVS_HIP(hipMemcpyAsync(h_out, d_stats, bytes, hipMemcpyDeviceToHost, ctx->stream));
   PVS_HIP(hipStreamSynchronize(ctx->stream));
   return PVS_OK;
 }

@@ -86,6 +86,8 @@ struct pvs_ctx {
   std::multimap<size_t, void*> block_cache;      // capacity -> block
   std::map<void*, size_t> block_size;            // live blocks handed out by table_alloc
   size_t block_cache_bytes = 0;
+  void* h_stage = nullptr;                        // pinned host staging block for small device -> host results (training statistics)
+  size_t h_stage_bytes = 0;
   double t_total[PVS_TIMER_SLOTS] = {0};
   int64_t t_count[PVS_TIMER_SLOTS] = {0};
 };
