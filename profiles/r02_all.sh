@@ -20,9 +20,9 @@ elif [ "$part" = "2" ]; then
   bash profiles/collect.sh r02 fp16sim --workload fp16sim --images 32768 > gpurun_out/collect_fp16sim.log 2>&1; echo fp16sim done
   python3 bench.py --workload learn --no-cpu-baseline > gpurun_out/learn.json 2> gpurun_out/learn.err; cp gpurun_out/learn.json profiles/r02_learn_bench.json; echo learn done
 else
-  python3 bench.py --workload corpus1m --images 1000000 --steps 1 --warmup 0 --retrieval filtered --queries 8192 > gpurun_out/c1m_filtered.json 2> gpurun_out/c1m_filtered.err
+  python3 bench.py --workload corpus1m --images 1000000 --steps 1 --warmup 1 --retrieval filtered --queries 8192 > gpurun_out/c1m_filtered.json 2> gpurun_out/c1m_filtered.err
   cp gpurun_out/c1m_filtered.json profiles/r02_corpus1m_filtered_bench.json; tail -c 1500 gpurun_out/c1m_filtered.json
-  python3 bench.py --workload corpus1m --images 1000000 --steps 1 --warmup 0 --retrieval f16 --queries 65536 > gpurun_out/c1m_f16.json 2> gpurun_out/c1m_f16.err
+  python3 bench.py --workload corpus1m --images 1000000 --steps 1 --warmup 1 --retrieval f16 --queries 65536 > gpurun_out/c1m_f16.json 2> gpurun_out/c1m_f16.err
   cp gpurun_out/c1m_f16.json profiles/r02_corpus1m_f16_bench.json; tail -c 1500 gpurun_out/c1m_f16.json
 fi
 cp profiles/r02_* gpurun_out/ 2>/dev/null || true
