@@ -29,5 +29,7 @@ elif [ "$part" = "4" ]; then
   # configs[4] at its real size on one GPU: every one of the 10^6 images is a query (about 65 s)
   python3 bench.py --workload corpus1m --images 1000000 --steps 1 --warmup 0 --retrieval f16 --queries 0 > gpurun_out/c1m_f16_full.json 2> gpurun_out/c1m_f16_full.err
   cp gpurun_out/c1m_f16_full.json profiles/r02_corpus1m_f16_full_bench.json; tail -c 1500 gpurun_out/c1m_f16_full.json
+  python3 bench.py --workload corpus1m --images 1000000 --steps 1 --warmup 0 --retrieval filtered --queries 0 > gpurun_out/c1m_filtered_full.json 2> gpurun_out/c1m_filtered_full.err
+  cp gpurun_out/c1m_filtered_full.json profiles/r02_corpus1m_filtered_full_bench.json; tail -c 1500 gpurun_out/c1m_filtered_full.json
 fi
 cp profiles/r02_* gpurun_out/ 2>/dev/null || true
