@@ -74,24 +74,57 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--images", type=int, default=8189)
+    ap.add_argument("--images", type=int, default=None, help="default: 8189 (configs[1]/[2]); 1,000,000 for --workload corpus1m")
     ap.add_argument("--desc", choices=["f32", "u8"], default="f32",
                     help="descriptor rows in HBM: fp32 RootSIFT (default) or raw uint8 SIFT with fused RootSIFT")
     ap.add_argument("--queries", type=int, default=0, help="query rows per rank (0 = every local image: all-vs-all)")
+    ap.add_argument("--total-queries", type=int, default=0,
+                    help="query rows over ALL ranks (strong scaling: each rank ranks total/N of them); overrides --queries")
     ap.add_argument("--fused", action="store_true", help="encode with the one-read fused kernel (PVS_OPT_VLAD_PATH = 3) instead of assign + aggregate")
-    ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim", "learn", "corpus1m"], default="config2",
-                    help="config2 = the headline line (default).  Side workloads (single GPU, same JSON shape, not the "
+    ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim", "learn", "corpus1m"], default=None,
+                    help="default: config2 (BASELINE configs[1], the headline) with --gpus 1; corpus1m (configs[3]/[4]: 1M images "
+                         "sharded over the ranks, fp16 exchange + retrieval, 65536 queries in all) with --gpus N > 1.  Side workloads (single GPU, same JSON shape, not the "
                          "headline): fisher = BASELINE configs[2] (Fisher D=512 K=256 n=196), vlad512 = the per-GPU share of "
                          "configs[3] (n=512 descriptors per image, encode only), fp16sim = configs[4] scaled to one GPU "
                          "(N x N cosine on fp16 encodings + top-10)")
-    ap.add_argument("--retrieval", choices=["exact", "filtered", "f16"], default="exact",
-                    help="exact = f32 MFMA GEMM over all pairs (the headline). filtered = the same top-k lists, bit for bit, "
+    ap.add_argument("--retrieval", choices=["exact", "filtered", "f16", "f64"], default=None,
+                    help="f64 (--workload fisher only) = float64 encodings scored and ranked in float64 on the f64 matrix pipe, the "
+                         "reference's dtype for Fisher vectors.  exact = f32 MFMA GEMM over all pairs (the headline). filtered = the same top-k lists, bit for bit, "
                          "through the fp16 prefilter + exact re-scoring (pvs_cosine_topk_filtered_dev); single GPU only. The "
                          "default run also times the filtered variant and reports it under 'filtered_retrieval'.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of cpu_baseline_subprocess()
     ap.add_argument("--pcie", action="store_true", help="also time one step with host-resident inputs (H2D included)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    # defaults that depend on the GPU count: the driver types `bench.py --gpus N --steps K --warmup W` and nothing else
+    args.workload_defaulted = args.workload is None
+    if args.workload is None:
+        args.workload = "config2" if args.gpus <= 1 else "corpus1m"
+    if args.images is None:
+        args.images = 1000000 if args.workload == "corpus1m" else 8189
+    if args.retrieval is None:
+        args.retrieval = "f16" if (args.workload == "corpus1m" and args.workload_defaulted) else "exact"
+    if args.workload == "corpus1m" and args.workload_defaulted and args.queries == 0 and args.total_queries == 0:
+        args.total_queries = 65536
+    if args.retrieval == "f64" and args.workload != "fisher":
+        ap.error("--retrieval f64 belongs to --workload fisher")
+    return args
+
+
+def self_launch(args):
+    """`python3 bench.py --gpus N` typed without a launcher: start the N ranks as FRESH processes (this one has not touched the
+    GPU and never will), one per GPU, through torch.distributed.run on 127.0.0.1; rank 0's JSON line goes to our stdout as it is
+    printed, the exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def make_corpus(n_images, seed, device):
@@ -169,10 +202,11 @@ def side_workload(args):
                 + torch.from_numpy(np.sqrt(cov).astype(np.float32)).to(dev)[z] * torch.randn((N * n, D), generator=g, device=dev))
         off = torch.arange(0, N + 1, dtype=torch.int64, device=dev) * n
         L = K + 2 * K * D
-        enc = torch.empty((N, L), dtype=torch.float32, device=dev)
-        inv = torch.empty((N,), dtype=torch.float32, device=dev)
+        f64 = args.retrieval == "f64"      # the reference's dtype: float64 encodings, float64 scores, float64 ranking
+        enc = torch.empty((N, L), dtype=torch.float64 if f64 else torch.float32, device=dev)
+        inv = torch.empty((N,), dtype=torch.float64 if f64 else torch.float32, device=dev)
         idx = torch.empty((N, TOPK), dtype=torch.int64, device=dev)
-        val = torch.empty((N, TOPK), dtype=torch.float32, device=dev)
+        val = torch.empty((N, TOPK), dtype=torch.float64 if f64 else torch.float32, device=dev)
         torch.cuda.synchronize()
         chunk = 32768
 
@@ -180,7 +214,12 @@ def side_workload(args):
             for s0 in range(0, N, chunk):
                 e0 = min(N, s0 + chunk)
                 ctx.fisher_encode_dev(gm, desc[s0 * n:].data_ptr(), DESC_F32, (off[s0:e0 + 1] - off[s0]).contiguous().data_ptr(),
-                                      e0 - s0, (e0 - s0) * n, enc[s0:].data_ptr(), 0)
+                                      e0 - s0, (e0 - s0) * n, enc[s0:].data_ptr(), 1 if f64 else 0)
+            if f64:
+                ctx.row_inv_norms_f64_dev(enc.data_ptr(), N, L, inv.data_ptr())
+                ctx.cosine_topk_f64_dev(enc.data_ptr(), N, enc.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(), TOPK,
+                                        idx.data_ptr(), val.data_ptr())
+                return
             ctx.row_inv_norms_dev(enc.data_ptr(), N, L, inv.data_ptr())
             if args.retrieval == "filtered":
                 fstat[0] = ctx.cosine_topk_filtered_dev(enc.data_ptr(), N, enc.data_ptr(), N, L, inv.data_ptr(), inv.data_ptr(), TOPK,
@@ -195,11 +234,22 @@ def side_workload(args):
         if fstat[0]:
             out["filtered_stats"] = fstat[0]
         enc_ms = st.get("fisher_posterior", 0) + st.get("fisher_moments", 0)
+        t128 = (N + 127) // 128
+        exec_flop = 2.0 * 128 * 128 * L * (t128 * (t128 + 1) // 2)     # the symmetric kernels run the upper triangle of tiles
+        gemm_ms = st.get("cosine_gemm", 0)
+        peak = 78.6 if f64 else FP32_MFMA_PEAK_TFLOPS
         out.update({"metric": "images/sec encoded + top-k retrieved, Fisher K256 D512 n196 (BASELINE configs[2])",
-                    "value": round(N / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "f64",
+                    "value": round(N / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3),
+                    "dtype": "f64" if f64 else "f32 (scores and stored encodings; the encode arithmetic is f64)",
                     "scaling": "strong", "stages_ms_per_step": st,
-                    "config": {"workload": f"{N} images x {n} x {D}-D descriptors, diag GMM K={K}: Fisher encode (fp64 "
-                                           f"arithmetic, fp32 stored) + {N}x{N} cosine + top-{TOPK}", "K": K, "D": D},
+                    "config": {"workload": f"{N} images x {n} x {D}-D descriptors, diag GMM K={K}: Fisher encode (fp64 arithmetic, "
+                                           f"{'fp64' if f64 else 'fp32'} stored) + {N}x{N} cosine in {'float64' if f64 else 'float32'} + top-{TOPK}",
+                               "K": K, "D": D},
+                    "roofline": {"kernel": "gemm_f64_kernel (v_mfma_f64_16x16x4_f64, symmetric)" if f64 else "gemm_mfma_kernel<128,128,f32> (symmetric)",
+                                 "bound": "mfma", "achieved": round(exec_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms else None,
+                                 "peak": peak, "unit": "TFLOP/s (executed: upper triangle of 128x128 tiles)",
+                                 "frac": round(exec_flop / (gemm_ms * 1e-3) / 1e12 / peak, 4) if gemm_ms else None, "traffic": None,
+                                 "algorithmic_equiv_TFLOPs": round(2.0 * N * N * L / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms else None},
                     "encode_GFLOPs_fp64": round(8.0 * n * K * D * N / (enc_ms * 1e-3) / 1e9, 1) if enc_ms else None})
     elif args.workload == "vlad512":
         n = 512
@@ -373,14 +423,19 @@ def rccl_unique_id(rank, world):
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        return cpu_baseline_child(args.images)
+        return cpu_baseline_child(args.images, args.total_queries or args.images, "fixed512" if args.workload == "corpus1m" else "ragged")
     if args.workload not in ("config2", "corpus1m"):
         return side_workload(args)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                      # no GPU call has happened in this process
     corpus1m = args.workload == "corpus1m"
     cpu = None
-    if (not corpus1m and not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1
-            and os.environ.get("PVS_BENCH_FORCE_DIST") != "1"):
-        cpu = cpu_baseline_subprocess(args.images)      # before anything touches the GPU: the child forks worker processes
+    if (not args.no_cpu_baseline and int(os.environ.get("RANK", "0")) == 0 and os.environ.get("PVS_BENCH_FORCE_DIST") != "1"
+            and os.environ.get("PVS_BENCH_BACKEND", "rccl") != "gloo"):
+        # rank 0 only, before anything touches the GPU (the child forks worker processes); the other ranks wait for it at the
+        # communicator bootstrap
+        q_cpu = args.total_queries if args.total_queries > 0 else (args.queries * int(os.environ.get("WORLD_SIZE", "1")) or args.images)
+        cpu = cpu_baseline_subprocess(args.images, min(q_cpu, args.images) if not corpus1m else q_cpu, "fixed512" if corpus1m else "ragged")
     import torch
     import pvsim
     from pvsim import distributed as pd
@@ -389,8 +444,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.gpus != world and not (world == 1 and os.environ.get("PVS_BENCH_FORCE_DIST") == "1"):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: start `python3 bench.py --gpus N` without a launcher (it starts "
+                         "its own ranks) or with torch.distributed.run --nproc-per-node N")
     # PVS_BENCH_BACKEND=gloo: REHEARSAL (ranks share the visible GPUs, host-staged collectives, see GlooStagedComm)
     backend = os.environ.get("PVS_BENCH_BACKEND", "rccl")
     # PVS_BENCH_FORCE_DIST=1 (started through torch.distributed.run with ONE rank): the multi-rank code path -- RCCL communicator
@@ -452,6 +508,8 @@ def main():
         enc16_loc = torch.empty((per, L), dtype=torch.float16, device=dev)
         enc16_all = torch.empty((world * per, L), dtype=torch.float16, device=dev) if multi else enc16_loc
     nq = n_loc if args.queries <= 0 else min(n_loc, args.queries)            # query rows of this rank (all of them by default)
+    if args.total_queries > 0:                                               # strong scaling: the queries are shared out
+        nq = max(1, min(n_loc, args.total_queries // world))
     idx = torch.empty((max(n_loc, 1), k_top), dtype=torch.int64, device=dev)
     val = torch.empty((max(n_loc, 1), k_top), dtype=torch.float32, device=dev)
 
@@ -701,6 +759,7 @@ def main():
         **({"backend": "ONE-rank RCCL self-check of the multi-rank path: not a measurement"} if forced else {}),
         **({"backend": "gloo REHEARSAL (ranks share GPUs, host-staged collectives): not a measurement"} if staged else {}),
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "queries_per_step": int(nq * world if multi else nq),
         "dtype": "f16" if retr == "f16" else "f32", "data": "synthetic", "retrieval": retr,
         "config": {"workload": workload, "images": N, "descriptors_rank0": total_desc, "descriptor_rows": "u8" if corpus1m else args.desc,
                    "K": K_CLUSTERS, "D": DIM, "topk": k_top, "parallelism": f"image-sharded x{world}",
@@ -751,8 +810,12 @@ def main():
         ctx.cosine_topk(v, v, TOPK)
         out["pcie_inclusive_images_per_s"] = round(N / (time.perf_counter() - t1), 1)
 
-    if cpu is not None and not multi:
-        out["cpu_baseline"] = cpu
+    if cpu is not None:
+        out["cpu_baseline"] = cpu       # single-process baseline of the same workload, timed on rank 0's host cores
+    if multi and not (staged or forced):
+        base = strong_scaling_base(args, retr)
+        if base is not None:
+            out["strong_scaling_base_1gpu"] = base
 
     print(json.dumps(out))
     if comm is not None:
@@ -796,7 +859,7 @@ def _w_init(centroids, one_thread=True):
 def _w_encode(job):
     seed, n_img = job
     orc, synth = _W["orc"], _W["synth"]
-    counts = synth.ragged_counts(n_img, seed)
+    counts = synth.ragged_counts(n_img, seed) if _W.get("gen", "ragged") == "ragged" else [512] * n_img
     rng = np.random.default_rng(seed)
     raws = [synth.sift_like(int(c), rng) for c in counts]
     t0 = time.perf_counter()
@@ -805,41 +868,59 @@ def _w_encode(job):
 
 
 def _w_query(job):
-    lo, hi = job
+    lo, n = job
     orc, db = _W["orc"], _W["db"]
     t0 = time.perf_counter()
-    for i in range(lo, hi):
-        orc.retrieve_top_k(db[i], db, TOPK)
+    for i in range(lo, lo + n):
+        orc.retrieve_top_k(db[i % len(db)], db, TOPK)
     return time.perf_counter() - t0
 
 
-def cpu_baseline_child(n_full):
-    """Runs in the child process: prints one JSON object."""
+def _host_cpus():
+    """-> (cpus this process may run on, the cgroup's CPU quota in cores or None)"""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            a, b = f.read().split()[:2]
+        if a != "max":
+            quota = float(a) / float(b)
+    except (OSError, ValueError):
+        pass
+    return avail, quota
+
+
+def cpu_baseline_child(n_full, n_queries, gen):
+    """Runs in the child process: prints one JSON object.  n_full images in the corpus, n_queries of them queried per step;
+    gen = "ragged" (configs[1]) or "fixed512" (configs[3]: 512 descriptors per image)."""
     import multiprocessing as mp
     import platform
     tables = np.load(os.path.join(REPO, "tests", "golden", "tables_k256_d128.npz"), allow_pickle=False)
     C = np.ascontiguousarray(tables["centroids"], dtype=np.float32)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    P = max(1, min(cores, 64))
+    cores, quota = _host_cpus()
+    # BASELINE.md section 3, mode B: os.cpu_count() workers -- the CPUs this process may actually use (affinity mask, and the
+    # cgroup quota where one is set: more workers than that only time-slice)
+    P = max(1, cores if quota is None else min(cores, int(np.ceil(quota))))
+    _W["gen"] = gen
     # ---- mode B first (it also builds the database): P single-thread workers
     ctx = mp.get_context("fork")
-    per = max(1, CPU_DB_ROWS // P)
+    per = max(2, -(-CPU_DB_ROWS // P))
     jobs = [(9000 + i, per) for i in range(P)]
     t0 = time.perf_counter()
     with ctx.Pool(P, initializer=_w_init, initargs=(C,)) as pool:
         parts = pool.map(_w_encode, jobs)
     wall_b_enc = time.perf_counter() - t0
-    db = np.ascontiguousarray(np.vstack([p[0] for p in parts]))
+    db = np.ascontiguousarray(np.vstack([p[0] for p in parts])[:max(CPU_DB_ROWS, 8 * P)])
     n_b = db.shape[0]
-    mean_desc = sum(p[2] for p in parts) / n_b
+    mean_desc = sum(p[2] for p in parts) / (per * P)
     # wall time includes the worker start-up; the workers' own clocks give the steady-state rate
     enc_b = max(p[1] for p in parts) / per / P * 1.0      # seconds per image at P-way throughput
     _W["db"] = db
-    q_per = 2
-    qjobs = [(i * q_per, (i + 1) * q_per) for i in range(P)]
+    q_per = 8
+    qjobs = [((i * q_per) % n_b, q_per) for i in range(P)]
     with ctx.Pool(P, initializer=_w_init, initargs=(C,)) as pool:
         t0 = time.perf_counter()
         qt = pool.map(_w_query, qjobs)
@@ -860,36 +941,66 @@ def cpu_baseline_child(n_full):
     for i in range(nq_a):
         _W["orc"].retrieve_top_k(db[i], db, TOPK)
     ret_a = (time.perf_counter() - t0) / nq_a * (n_full / n_b)
-    out = {"value": round(1.0 / (enc_b + ret_b), 2), "unit": "images/s", "cores": P, "kind": "port",
-           "sample": f"NumPy restatement of the reference's procedure (oracle/pvsim_oracle.py). Mode B (value): {P} worker processes, 1 BLAS "
-                     f"thread each: {n_b} ragged images encoded (mean {mean_desc:.0f} descriptors), {P * q_per} queries ranked against the "
-                     f"{n_b}-row database; per-query cost scaled x{n_full / n_b:.2f} to the {n_full}-row database. Mode A: one process, "
-                     f"library-default threads: {n_a} images encoded, {nq_a} queries",
-           "mode_B": {"images_per_s": round(1.0 / (enc_b + ret_b), 2), "encode_images_per_s": round(1.0 / enc_b, 1),
-                      "retrieve_queries_per_s": round(1.0 / ret_b, 2), "workers": P, "threads_per_worker": 1,
-                      "encode_wall_s_incl_startup": round(wall_b_enc, 2), "query_wall_s": round(wall_b_q, 2)},
-           "mode_A": {"images_per_s": round(1.0 / (enc_a + ret_a), 2), "encode_images_per_s": round(1.0 / enc_a, 1),
-                      "retrieve_queries_per_s": round(1.0 / ret_a, 2), "threadpools": pools},
-           "host": {"cpus_available": cores, "os_cpu_count": os.cpu_count(), "machine": platform.processor() or platform.machine(),
-                    "numpy": np.__version__}}
+    qf = n_queries / n_full                               # queries per image of the corpus in one step
+    phys = None
     try:
         with open("/proc/cpuinfo") as f:
-            names = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")]
-        out["host"]["cpu_model"] = names[0] if names else None
+            txt = f.read()
+        ids = set()
+        cur = {}
+        for line in txt.splitlines():
+            if ":" in line:
+                k_, v_ = [x.strip() for x in line.split(":", 1)]
+                cur[k_] = v_
+            elif cur:
+                ids.add((cur.get("physical id"), cur.get("core id")))
+                cur = {}
+        phys = len(ids) if ids else None
+        names = [l.split(":", 1)[1].strip() for l in txt.splitlines() if l.startswith("model name")]
     except OSError:
-        pass
+        names = []
+    out = {"value": round(1.0 / (enc_b + qf * ret_b), 2), "unit": "images/s", "cores": P, "kind": "port",
+           "sample": f"NumPy restatement of the reference's procedure (oracle/pvsim_oracle.py). Mode B (value): {P} worker processes, 1 BLAS "
+                     f"thread each: {per * P} images encoded (mean {mean_desc:.0f} descriptors), {P * q_per} queries ranked against a "
+                     f"{n_b}-row database; per-query cost scaled x{n_full / n_b:.2f} to the {n_full}-row database, {n_queries} queries per "
+                     f"{n_full}-image step. Mode A: one process, library-default threads: {n_a} images encoded, {nq_a} queries",
+           "mode_B": {"images_per_s": round(1.0 / (enc_b + qf * ret_b), 2), "encode_images_per_s": round(1.0 / enc_b, 1),
+                      "retrieve_queries_per_s": round(1.0 / ret_b, 3), "workers": P, "threads_per_worker": 1, "queries_per_worker": q_per,
+                      "encode_wall_s_incl_startup": round(wall_b_enc, 2), "query_wall_s": round(wall_b_q, 2)},
+           "mode_A": {"images_per_s": round(1.0 / (enc_a + qf * ret_a), 2), "encode_images_per_s": round(1.0 / enc_a, 1),
+                      "retrieve_queries_per_s": round(1.0 / ret_a, 3), "threadpools": pools},
+           "host": {"cpus_available": cores, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count(), "physical_cores": phys,
+                    "machine": platform.processor() or platform.machine(), "numpy": np.__version__,
+                    "cpu_model": names[0] if names else None}}
     print(json.dumps(out))
 
 
-def cpu_baseline_subprocess(n_full):
+def cpu_baseline_subprocess(n_full, n_queries=None, gen="ragged"):
     """Start the CPU baseline as a child process.  Must be called BEFORE this process initialises the GPU."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--images", str(n_full)],
-                       capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--images", str(n_full),
+                        "--total-queries", str(n_full if n_queries is None else n_queries), "--workload",
+                        "corpus1m" if gen == "fixed512" else "config2"],
+                       capture_output=True, text=True, timeout=1500)
     if r.returncode != 0:
         return {"error": r.stderr[-800:]}
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return json.loads(lines[-1]) if lines else {"error": "no output"}
+
+
+def strong_scaling_base(args, retr):
+    """The committed one-GPU run of the SAME workload and flags (profiles/rNN_corpus1m_base_bench.json), so that an N > 1 line
+    carries the base its strong scaling is measured from (the driver's own N = 1 run is the configs[1] headline)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_corpus1m_base_bench.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if (d["config"]["images"] == args.images and d.get("retrieval") == retr and d.get("n_gpus") == 1
+                    and d.get("queries_per_step") == max(1, args.total_queries)):
+                return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "source": os.path.basename(f)}
+        except Exception:
+            continue
+    return None
 
 
 if __name__ == "__main__":

@@ -187,11 +187,20 @@ int pvs_cosine_topk_f16_dev(pvs_ctx* ctx, const void* d_Q16, int64_t nq, const v
 int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L, int k,
                     int64_t* out_idx, float* out_val);
 /* float64 operands (Fisher encodings): the reference scores and ranks in float64 unless BOTH operands are float32
- * (pyvisim/_utils.py:312-330 -> sklearn cosine_similarity; eval.py:37-43,75-80,131-132 argsort that array).  Host pointers;
- * out_val float64 [nq][k], same order as the fp32 entry points (score descending, index ascending, NaN last).
- * k <= 4096 when N > 8192 (PVS_ERR_UNSUPPORTED otherwise). */
+ * (pyvisim/_utils.py:312-330 -> sklearn cosine_similarity; eval.py:37-43,75-80,131-132 argsort that array).  The GEMM runs
+ * on the f64 matrix pipe (v_mfma_f64_16x16x4_f64, fixed k order, upper triangle + mirror when Q == DB); rows must be 16-B
+ * aligned with an even L for that path (anything else takes a vector-ALU tile kernel).  out_val float64 [nq][k], same order
+ * as the fp32 entry points (score descending, index ascending, NaN last); any 1 <= k <= N (deep rankings page through the
+ * complete score rows, as top_k_map(k=None) needs).
+ * pvs_cosine_topk_f64: host pointers, the database is uploaded once per call.  The _dev forms take device pointers and the
+ * 1/||row|| factors (pvs_row_inv_norms_f64_dev; NULL = 1), keep everything resident and do not synchronise. */
 int pvs_cosine_topk_f64(pvs_ctx* ctx, const double* Q, int64_t nq, const double* DB, int64_t N, int64_t L, int k,
                         int64_t* out_idx, double* out_val);
+int pvs_row_inv_norms_f64_dev(pvs_ctx* ctx, const double* d_x, int64_t rows, int64_t L, double* d_inv);
+int pvs_cosine_f64_dev(pvs_ctx* ctx, const double* d_A, int64_t M, const double* d_B, int64_t N, int64_t L,
+                       const double* d_inv_a, const double* d_inv_b, double* d_out, int64_t ldo);
+int pvs_cosine_topk_f64_dev(pvs_ctx* ctx, const double* d_Q, int64_t nq, const double* d_DB, int64_t N, int64_t L,
+                            const double* d_inv_q, const double* d_inv_db, int k, int64_t* d_idx, double* d_val);
 /* The same lists as pvs_cosine_topk_dev(col_offset 0, merge 0) -- bit-identical indices AND scores -- computed faster:
  * all pairs are scored with fp16 operands under a proven error bound, the columns within twice that bound of each query's
  * approximate k-th best are re-scored with the exact fp32 recurrence of the f32 GEMM kernel, and those are ranked.
@@ -278,12 +287,6 @@ int pvs_kmeanspp_run_dev(pvs_ctx* ctx, const float* d_x, int D, int64_t total_de
 int pvs_timers_enable(pvs_ctx* ctx, int on);
 int pvs_timers_reset(pvs_ctx* ctx);
 int pvs_timers_read(pvs_ctx* ctx, int which, double* total_ms, int64_t* launches);
-
-/* Diagnostic build of the fused VLAD encode (in-kernel cycle stamps of one wave per workgroup; the product kernel carries
- * none).  enable != 0: following fused launches run the stamped kernel and add into 16 counters; out16 (optional) receives and
- * resets them: [0..6] shader cycles in P0 / A / reduce / exact re-evaluation / K2 / epilogue / image switch summed over the
- * workgroups, [8] stages, [9] stages with a re-evaluation, [10] re-evaluation entries, [11] rows the margin did not settle. */
-int pvs_fused_profile(pvs_ctx* ctx, int enable, int64_t* out16);
 
 #ifdef __cplusplus
 }

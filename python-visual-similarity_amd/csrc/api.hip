@@ -957,7 +957,53 @@ PVS_EXPORT int pvs_cosine_topk(pvs_ctx* ctx, const float* Q, int64_t nq, const f
 }
 
 
-// float64 scores + ranking (the reference's dtype rule for Fisher encodings); query rows go through in panels of <= 256 MiB
+// ---------------------------------------------------------------- float64 scores + ranking (Fisher encodings)
+PVS_EXPORT int pvs_row_inv_norms_f64_dev(pvs_ctx* ctx, const double* d_x, int64_t rows, int64_t L, double* d_inv) {
+  PVS_NEED(ctx, "ctx");
+  if (rows <= 0) return PVS_OK;
+  PVS_NEED(d_x, "x");
+  PVS_NEED(d_inv, "inv");
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_row_inv_norms_f64(ctx, d_x, rows, L, d_inv);
+}
+
+PVS_EXPORT int pvs_cosine_f64_dev(pvs_ctx* ctx, const double* d_A, int64_t M, const double* d_B, int64_t N, int64_t L,
+                                  const double* d_inv_a, const double* d_inv_b, double* d_out, int64_t ldo) {
+  PVS_NEED(ctx, "ctx");
+  if (M <= 0 || N <= 0) return PVS_OK;
+  PVS_NEED(d_A, "A");
+  PVS_NEED(d_B, "B");
+  PVS_NEED(d_out, "out");
+  if (ldo < N) PVS_FAIL(PVS_ERR_INVALID, "cosine: ldo (%lld) < N (%lld)", (long long)ldo, (long long)N);
+  PVS_HIP(hipSetDevice(ctx->device));
+  return launch_cosine_f64_dev(ctx, d_A, M, d_B, N, L, d_inv_a, d_inv_b, d_out, ldo);
+}
+
+// GEMM panel (complete rows: the ranking pages through them) + rank, tiled over the queries; panel <= 1 GiB of float64
+PVS_EXPORT int pvs_cosine_topk_f64_dev(pvs_ctx* ctx, const double* d_Q, int64_t nq, const double* d_DB, int64_t N, int64_t L,
+                                       const double* d_inv_q, const double* d_inv_db, int k, int64_t* d_idx, double* d_val) {
+  PVS_NEED(ctx, "ctx");
+  if (nq <= 0) return PVS_OK;
+  PVS_NEED(d_Q, "Q");
+  PVS_NEED(d_DB, "DB");
+  PVS_NEED(d_idx, "idx");
+  PVS_NEED(d_val, "val");
+  if (N <= 0) PVS_FAIL(PVS_ERR_INVALID, "empty database");
+  if (k < 1 || k > N) PVS_FAIL(PVS_ERR_INVALID, "k = %d out of range 1..%lld", k, (long long)N);
+  PVS_HIP(hipSetDevice(ctx->device));
+  const int64_t QT = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)128 << 20) / N));
+  double* panel = nullptr;
+  PVS_TRY(ws_reserve(ctx, 2, (size_t)QT * N * sizeof(double), reinterpret_cast<void**>(&panel)));
+  for (int64_t q0 = 0; q0 < nq; q0 += QT) {
+    const int64_t qn = std::min(QT, nq - q0);
+    // the whole problem in one panel and Q == DB: the symmetric kernel (launch_cosine_f64_dev detects it)
+    PVS_TRY(launch_cosine_f64_dev(ctx, d_Q + q0 * L, qn, d_DB, N, L, d_inv_q ? d_inv_q + q0 : nullptr, d_inv_db, panel, N));
+    PVS_TRY(launch_rank_f64(ctx, panel, qn, N, N, k, d_idx + q0 * k, d_val + q0 * k));
+  }
+  return PVS_OK;
+}
+
+// host pointers: the database is uploaded ONCE per call, the queries in blocks; norms, panels and lists stay on the device
 PVS_EXPORT int pvs_cosine_topk_f64(pvs_ctx* ctx, const double* Q, int64_t nq, const double* DB, int64_t N, int64_t L, int k,
                                    int64_t* out_idx, double* out_val) {
   PVS_NEED(ctx, "ctx");
@@ -970,27 +1016,34 @@ PVS_EXPORT int pvs_cosine_topk_f64(pvs_ctx* ctx, const double* Q, int64_t nq, co
   if (N <= 0) PVS_FAIL(PVS_ERR_INVALID, "empty database");
   if (k < 1 || k > N) PVS_FAIL(PVS_ERR_INVALID, "k = %d out of range 1..%lld", k, (long long)N);
   PVS_HIP(hipSetDevice(ctx->device));
-  const int64_t QT = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)32 << 20) / N));
-  const size_t db_bytes = ((size_t)N * L * 8 + 255) / 256 * 256, q_bytes = ((size_t)QT * L * 8 + 255) / 256 * 256;
+  const bool same = (Q == DB && nq == N);
+  // query block: as many rows as one score panel of pvs_cosine_topk_f64_dev holds, at most 2 GiB of rows
+  const int64_t QB = same ? nq : std::max<int64_t>(1, std::min<int64_t>(nq, std::min<int64_t>(((int64_t)128 << 20) / N,
+                                                                                             ((int64_t)256 << 20) / L)));
+  const size_t db_bytes = ((size_t)N * L * 8 + 255) / 256 * 256, q_bytes = same ? 0 : ((size_t)QB * L * 8 + 255) / 256 * 256;
   char* d_in = nullptr;
   char* d_s = nullptr;
   PVS_TRY(ws_reserve(ctx, 0, db_bytes + q_bytes, reinterpret_cast<void**>(&d_in)));
-  const size_t panel_b = ((size_t)QT * N * 8 + 255) / 256 * 256, idx_b = ((size_t)QT * k * 8 + 255) / 256 * 256;
-  PVS_TRY(ws_reserve(ctx, 2, panel_b + 2 * idx_b, reinterpret_cast<void**>(&d_s)));
+  const size_t nrm_b = ((size_t)(N + QB) * 8 + 255) / 256 * 256, idx_b = ((size_t)QB * k * 8 + 255) / 256 * 256;
+  PVS_TRY(ws_reserve(ctx, 6, nrm_b + 2 * idx_b, reinterpret_cast<void**>(&d_s)));
   double* d_db = reinterpret_cast<double*>(d_in);
-  double* d_q = reinterpret_cast<double*>(d_in + db_bytes);
-  double* panel = reinterpret_cast<double*>(d_s);
-  int64_t* d_idx = reinterpret_cast<int64_t*>(d_s + panel_b);
-  double* d_val = reinterpret_cast<double*>(d_s + panel_b + idx_b);
+  double* d_q = same ? d_db : reinterpret_cast<double*>(d_in + db_bytes);
+  double* inv_db = reinterpret_cast<double*>(d_s);
+  double* inv_q = same ? inv_db : inv_db + N;
+  int64_t* d_idx = reinterpret_cast<int64_t*>(d_s + nrm_b);
+  double* d_val = reinterpret_cast<double*>(d_s + nrm_b + idx_b);
   PVS_HIP(hipMemcpyAsync(d_db, DB, (size_t)N * L * 8, hipMemcpyHostToDevice, ctx->stream));
-  for (int64_t q0 = 0; q0 < nq; q0 += QT) {
-    const int64_t qn = std::min(QT, nq - q0);
-    PVS_HIP(hipMemcpyAsync(d_q, Q + q0 * L, (size_t)qn * L * 8, hipMemcpyHostToDevice, ctx->stream));
-    PVS_TRY(launch_cosine_f64(ctx, d_q, qn, d_db, N, L, panel));
-    PVS_TRY(launch_rank_f64(ctx, panel, qn, N, N, k, d_idx, d_val));
+  PVS_TRY(launch_row_inv_norms_f64(ctx, d_db, N, L, inv_db));
+  for (int64_t q0 = 0; q0 < nq; q0 += QB) {
+    const int64_t qn = std::min(QB, nq - q0);
+    if (!same) {
+      PVS_HIP(hipMemcpyAsync(d_q, Q + q0 * L, (size_t)qn * L * 8, hipMemcpyHostToDevice, ctx->stream));
+      PVS_TRY(launch_row_inv_norms_f64(ctx, d_q, qn, L, inv_q));
+    }
+    PVS_TRY(pvs_cosine_topk_f64_dev(ctx, d_q, qn, d_db, N, L, inv_q, inv_db, k, d_idx, d_val));
     PVS_HIP(hipMemcpyAsync(out_idx + q0 * k, d_idx, (size_t)qn * k * 8, hipMemcpyDeviceToHost, ctx->stream));
     PVS_HIP(hipMemcpyAsync(out_val + q0 * k, d_val, (size_t)qn * k * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PVS_HIP(hipStreamSynchronize(ctx->stream));   // d_q and the panel are reused by the next batch
+    PVS_HIP(hipStreamSynchronize(ctx->stream));   // d_q and the lists are reused by the next block
   }
   return PVS_OK;
 }

@@ -116,6 +116,17 @@ static int load_rccl() {
     if (r__ != ncclSuccess) PVS_FAIL(PVS_ERR_NO_DEVICE, "%s failed: %s", #expr, g_rccl.GetErrorString(r__)); \
   } while (0)
 
+// inside ncclGroupStart / ncclGroupEnd: remember the first failure and keep going, so that the group is always closed
+// (a Send / Recv that fails must not leave the group open: the next collective would be queued into it or hang)
+#define PVS_NCCL_IN_GROUP(first, expr)                                                            \
+  do {                                                                                            \
+    ncclResult_t r__ = (expr);                                                                    \
+    if (r__ != ncclSuccess && (first) == ncclSuccess) {                                           \
+      (first) = r__;                                                                              \
+      ::pvs::set_error("%s failed: %s", #expr, g_rccl.GetErrorString(r__));                       \
+    }                                                                                             \
+  } while (0)
+
 }  // namespace pvs
 
 using namespace pvs;
@@ -189,12 +200,13 @@ PVS_EXPORT int pvs_alltoall_dev(pvs_comm* c, const void* d_send, void* d_recv, s
   const char* s = static_cast<const char*>(d_send);
   char* r = static_cast<char*>(d_recv);
   PVS_NCCL(g_rccl.GroupStart());
-  for (int p = 0; p < c->nranks; ++p) {
-    PVS_NCCL(g_rccl.Send(s + (size_t)p * bytes_per_rank, bytes_per_rank, ncclUint8, p, c->comm, c->ctx->stream));
-    PVS_NCCL(g_rccl.Recv(r + (size_t)p * bytes_per_rank, bytes_per_rank, ncclUint8, p, c->comm, c->ctx->stream));
+  ncclResult_t first = ncclSuccess;
+  for (int p = 0; p < c->nranks && first == ncclSuccess; ++p) {
+    PVS_NCCL_IN_GROUP(first, g_rccl.Send(s + (size_t)p * bytes_per_rank, bytes_per_rank, ncclUint8, p, c->comm, c->ctx->stream));
+    PVS_NCCL_IN_GROUP(first, g_rccl.Recv(r + (size_t)p * bytes_per_rank, bytes_per_rank, ncclUint8, p, c->comm, c->ctx->stream));
   }
-  PVS_NCCL(g_rccl.GroupEnd());
-  return PVS_OK;
+  PVS_NCCL_IN_GROUP(first, g_rccl.GroupEnd());
+  return first == ncclSuccess ? PVS_OK : PVS_ERR_NO_DEVICE;
 }
 
 PVS_EXPORT int pvs_sendrecv_dev(pvs_comm* c, int n_ops, const int* peers, const void* const* d_send, const size_t* send_bytes,
@@ -203,19 +215,18 @@ PVS_EXPORT int pvs_sendrecv_dev(pvs_comm* c, int n_ops, const int* peers, const 
   if (n_ops <= 0) return PVS_OK;
   PVS_NEEDC(peers, "peers");
   PVS_HIP(hipSetDevice(c->ctx->device));
+  for (int i = 0; i < n_ops; ++i)
+    if (peers[i] < 0 || peers[i] >= c->nranks) PVS_FAIL(PVS_ERR_INVALID, "peer %d out of range", peers[i]);
   PVS_NCCL(g_rccl.GroupStart());
-  for (int i = 0; i < n_ops; ++i) {
-    if (peers[i] < 0 || peers[i] >= c->nranks) {
-      g_rccl.GroupEnd();
-      PVS_FAIL(PVS_ERR_INVALID, "peer %d out of range", peers[i]);
-    }
+  ncclResult_t first = ncclSuccess;
+  for (int i = 0; i < n_ops && first == ncclSuccess; ++i) {
     if (d_send && send_bytes && send_bytes[i] > 0)
-      PVS_NCCL(g_rccl.Send(d_send[i], send_bytes[i], ncclUint8, peers[i], c->comm, c->ctx->stream));
+      PVS_NCCL_IN_GROUP(first, g_rccl.Send(d_send[i], send_bytes[i], ncclUint8, peers[i], c->comm, c->ctx->stream));
     if (d_recv && recv_bytes && recv_bytes[i] > 0)
-      PVS_NCCL(g_rccl.Recv(d_recv[i], recv_bytes[i], ncclUint8, peers[i], c->comm, c->ctx->stream));
+      PVS_NCCL_IN_GROUP(first, g_rccl.Recv(d_recv[i], recv_bytes[i], ncclUint8, peers[i], c->comm, c->ctx->stream));
   }
-  PVS_NCCL(g_rccl.GroupEnd());
-  return PVS_OK;
+  PVS_NCCL_IN_GROUP(first, g_rccl.GroupEnd());
+  return first == ncclSuccess ? PVS_OK : PVS_ERR_NO_DEVICE;
 }
 
 PVS_EXPORT int pvs_allreduce_max_f64(pvs_comm* c, double* h_inout, int count) {

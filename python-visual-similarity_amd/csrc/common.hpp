@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/pvsim.h"
+#include "../../include/pvsim_diag.h"
 
 #define PVS_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -70,7 +71,7 @@ struct pvs_ctx {
     int n_main = 0, n_tail = 0, splitk = 1;
     void* d_tiles = nullptr;
     size_t cap = 0;
-  } gemm_plan[3];
+  } gemm_plan[4];   // 0 exact fp32, 1 fp16 256x256, 2 fp16 128x128 two-level, 3 float64
   // dynamic-LDS limits already raised on this context's device: kernel -> bytes
   std::map<const void*, int> lds_attr;
   // behaviour switches (pvs_set_option); defaults = the product path
@@ -218,6 +219,9 @@ int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const 
                                 const float* invq, const float* invdb, int k, int64_t col_offset, int64_t* d_idx, float* d_val,
                                 int64_t* h_stats);
 int launch_cosine_f64(pvs_ctx* ctx, const double* A, int64_t M, const double* B, int64_t N, int64_t L, double* out);
+int launch_row_inv_norms_f64(pvs_ctx* ctx, const double* d_x, int64_t rows, int64_t L, double* d_inv);
+int launch_cosine_f64_dev(pvs_ctx* ctx, const double* A, int64_t M, const double* B, int64_t N, int64_t L, const double* inva,
+                          const double* invb, double* out, int64_t ldo);
 int launch_topk(pvs_ctx* ctx, const float* scores, int64_t nq, int64_t ncols, int64_t ld, int k,
                 int64_t col_offset, int merge, int64_t* d_idx, float* d_val);
 int launch_topk_merge(pvs_ctx* ctx, const int64_t* idx_lists, const float* val_lists, int n_lists, int64_t nq,

@@ -14,6 +14,7 @@
 
 #include "common.hpp"
 #include "gemm_mfma.hpp"
+#include "gemm_f64.hpp"
 
 namespace pvs {
 
@@ -338,20 +339,86 @@ int launch_cosine_f32_dual(pvs_ctx* ctx, const float* A, int64_t M, const float*
   return cosine_mfma<0>(ctx, A, M, B, N, L, inva, invb, out, ldo, out_t, ldt);
 }
 
+// ------------------------------------------------------------------------------------- float64 on the f64 matrix pipe
+int launch_row_inv_norms_f64(pvs_ctx* ctx, const double* d_x, int64_t rows, int64_t L, double* d_inv) {
+  if (rows <= 0) return PVS_OK;
+  ScopedTimer tm(ctx, T_MISC);
+  hipLaunchKernelGGL(row_inv_norms_generic_kernel<double>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, d_x, rows, L,
+                     d_inv);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+template <bool SYMM>
+static int launch_gemm_f64(pvs_ctx* ctx, GemmArgsF64 g, const GemmPlan& plan) {
+  using Cfg = GemmCfgF64;
+  auto kfull = gemm_f64_kernel<SYMM, GEMM_MODE_FULL>;
+  auto kpart = gemm_f64_kernel<SYMM, GEMM_MODE_PARTIAL>;
+  auto kred = gemm_f64_kernel<SYMM, GEMM_MODE_REDUCE>;
+  for (const void* k : {reinterpret_cast<const void*>(kfull), reinterpret_cast<const void*>(kpart), reinterpret_cast<const void*>(kred)})
+    PVS_TRY(ensure_lds(ctx, k, Cfg::LDS_BYTES));
+  if (plan.n_main > 0) {
+    g.tile_base = 0;
+    hipLaunchKernelGGL(kfull, dim3((unsigned)plan.n_main), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
+  }
+  if (plan.n_tail > 0) {
+    const int nk = (int)((g.L + Cfg::BK - 1) / Cfg::BK);
+    const int sk = std::max(1, std::min(plan.splitk, nk));
+    const size_t bytes = (size_t)plan.n_tail * sk * Cfg::PART_ELEMS * sizeof(double);
+    g.tile_base = plan.n_main;
+    if (sk == 1 || bytes > ((size_t)1 << 30)) {
+      hipLaunchKernelGGL(kfull, dim3((unsigned)plan.n_tail), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
+    } else {
+      double* part = nullptr;
+      PVS_TRY(ws_reserve(ctx, 4, bytes, reinterpret_cast<void**>(&part)));
+      g.splitk = sk;
+      g.nparts = sk;
+      g.partial = part;
+      hipLaunchKernelGGL(kpart, dim3((unsigned)(plan.n_tail * sk)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
+      hipLaunchKernelGGL(kred, dim3((unsigned)plan.n_tail), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
+    }
+  }
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
+
+// out[m*ldo + n] = (A_m . B_n) * inva[m] * invb[n], all float64, device pointers; inva / invb may be null (= 1)
+int launch_cosine_f64_dev(pvs_ctx* ctx, const double* A, int64_t M, const double* B, int64_t N, int64_t L, const double* inva,
+                          const double* invb, double* out, int64_t ldo) {
+  if (M <= 0 || N <= 0) return PVS_OK;
+  if (L <= 0) PVS_FAIL(PVS_ERR_INVALID, "cosine: L must be positive");
+  // MFMA path: 16-B aligned rows (even L), per-lane byte offsets inside a 128-row tile must fit 32 bits
+  const bool fast = (L % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
+                    (L <= (int64_t)4 * 1024 * 1024);
+  ScopedTimer tm(ctx, T_GEMM);
+  if (!fast) {
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+    hipLaunchKernelGGL(cosine_gemm_generic_kernel<double>, grid, dim3(256), 0, ctx->stream, A, M, B, N, L, inva, invb, out, ldo);
+    PVS_HIP(hipGetLastError());
+    return PVS_OK;
+  }
+  const int tiles_m = (int)((M + 127) / 128), tiles_n = (int)((N + 127) / 128);
+  if ((int64_t)tiles_m * tiles_n > 0x3fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "cosine: too many tiles for one launch");
+  const bool symm = (A == B) && (M == N) && (inva == invb);
+  GemmPlan* plan = nullptr;
+  PVS_TRY(build_plan(ctx, 3, tiles_m, tiles_n, symm, ctx->num_cu * 2, &plan));
+  GemmArgsF64 g{};
+  g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = L; g.ldb = L; g.inva = inva; g.invb = invb; g.out = out; g.ldo = ldo;
+  g.tiles = static_cast<const GemmTile*>(plan->d_tiles);
+  g.splitk = 1;
+  PVS_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(const_cast<float**>(&g.zero16)), HIP_SYMBOL(g_zero16)));
+  return symm ? launch_gemm_f64<true>(ctx, g, *plan) : launch_gemm_f64<false>(ctx, g, *plan);
+}
+
+// host-API form: norms of both operands (workspace slot 1), then the GEMM; out is M x N, ld = N
 int launch_cosine_f64(pvs_ctx* ctx, const double* A, int64_t M, const double* B, int64_t N, int64_t L, double* out) {
   if (M <= 0 || N <= 0) return PVS_OK;
   double* inv = nullptr;
+  const bool same = (A == B && M == N);
   PVS_TRY(ws_reserve(ctx, 1, (size_t)(M + N) * sizeof(double), reinterpret_cast<void**>(&inv)));
-  ScopedTimer tm(ctx, T_GEMM);
-  hipLaunchKernelGGL(row_inv_norms_generic_kernel<double>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, ctx->stream, A,
-                     M, L, inv);
-  hipLaunchKernelGGL(row_inv_norms_generic_kernel<double>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, B,
-                     N, L, inv + M);
-  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
-  hipLaunchKernelGGL(cosine_gemm_generic_kernel<double>, grid, dim3(256), 0, ctx->stream, A, M, B, N, L, inv, inv + M,
-                     out, N);
-  PVS_HIP(hipGetLastError());
-  return PVS_OK;
+  PVS_TRY(launch_row_inv_norms_f64(ctx, A, M, L, inv));
+  if (!same) PVS_TRY(launch_row_inv_norms_f64(ctx, B, N, L, inv + M));
+  return launch_cosine_f64_dev(ctx, A, M, B, N, L, inv, same ? inv : inv + M, out, N);
 }
 
 }  // namespace pvs

@@ -141,7 +141,8 @@ struct GemmLoader {
   int wave_base;       // byte offset of this wave's first load inside a stage buffer
   bool is_a;
 
-  __device__ __forceinline__ void init(const GemmArgs& g, int64_t m0, int64_t n0, int wave, int lane) {
+  template <class Args>
+  __device__ __forceinline__ void init(const Args& g, int64_t m0, int64_t n0, int wave, int lane) {
     wave_base = wave * LPW * 1024;
     is_a = wave * LPW < Cfg::A_INSTR;
     const int64_t row0 = is_a ? m0 : n0, nrows = is_a ? g.M : g.N, ld = is_a ? g.lda : g.ldb;
@@ -194,7 +195,8 @@ struct GemmLoader {
   }
 
   // last k-tile when L % BK != 0: 16-B chunks at or past L come from a zero buffer (builtin path, rare)
-  __device__ __forceinline__ void issue_checked(const GemmArgs& g, int64_t k0, char* stage) const {
+  template <class Args>
+  __device__ __forceinline__ void issue_checked(const Args& g, int64_t k0, char* stage) const {
 #pragma unroll
     for (int q = 0; q < LPW; ++q) {
       const char* p = (k0 + gce[q] < g.L) ? base + k0 * Cfg::ESZ + (size_t)voff[q] + (q & 3) * 1024

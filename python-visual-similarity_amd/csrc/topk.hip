@@ -345,13 +345,32 @@ __device__ __forceinline__ void bitonic_desc(uint64_t* key, uint32_t* id, int n2
   __syncthreads();
 }
 
+// One page of the ranking: the best `k` entries of the row that come strictly AFTER the entry at position off - 1 of the list
+// already written (off = 0: no bound), stored at positions [off, off + k) of a list of length ktotal.  Deep rankings
+// (top_k_map(k=None) is a full argsort in the reference, eval.py:78) page through the complete row R64_PAGE entries at a time.
 __global__ __launch_bounds__(R64_THREADS) void rank_f64_kernel(const double* __restrict__ scores, int64_t ncols, int64_t ld, int k,
-                                                               int64_t* __restrict__ oidx, double* __restrict__ oval) {
+                                                               int ktotal, int off, int64_t* __restrict__ oidx,
+                                                               double* __restrict__ oval) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t* key = reinterpret_cast<uint64_t*>(smem);               // [R64_CHUNK]
   uint32_t* id = reinterpret_cast<uint32_t*>(key + R64_CHUNK);     // [R64_CHUNK]
   const int64_t q = blockIdx.x;
   const double* row = scores + q * ld;
+  uint64_t bkey = ~0ull;
+  uint32_t bid = 0;
+  const bool bounded = off > 0;
+  if (bounded) {
+    const int64_t pi = oidx[q * ktotal + off - 1];
+    if (pi < 0) {                                                  // the previous page already ran out of columns
+      for (int t = threadIdx.x; t < k; t += R64_THREADS) {
+        oidx[q * ktotal + off + t] = -1;
+        oval[q * ktotal + off + t] = -INFINITY;
+      }
+      return;
+    }
+    bid = (uint32_t)pi;
+    bkey = mono_f64(row[pi]);
+  }
   int have = 0;   // entries of the running list, kept sorted in key[0..have)
   for (int64_t c0 = 0; c0 < ncols;) {
     // the running list stays in front; the rest of the buffer takes the next columns
@@ -360,8 +379,14 @@ __global__ __launch_bounds__(R64_THREADS) void rank_f64_kernel(const double* __r
     int n2 = 1;
     while (n2 < have + take) n2 <<= 1;
     for (int t = threadIdx.x; t < n2 - have; t += R64_THREADS) {
-      const bool in = t < take;
-      key[have + t] = in ? mono_f64(row[c0 + t]) : 0ull;            // 0: below NaN's key, never selected before a real entry
+      bool in = t < take;
+      uint64_t kk = 0ull;                                           // 0: below NaN's key, never selected before a real entry
+      if (in) {
+        kk = mono_f64(row[c0 + t]);
+        // entries at or before the bound in the total order (key descending, index ascending) belong to earlier pages
+        if (bounded && (kk > bkey || (kk == bkey && (uint32_t)(c0 + t) <= bid))) { in = false; kk = 0ull; }
+      }
+      key[have + t] = kk;
       id[have + t] = in ? (uint32_t)(c0 + t) : 0xffffffffu;
     }
     bitonic_desc(key, id, n2);
@@ -371,21 +396,28 @@ __global__ __launch_bounds__(R64_THREADS) void rank_f64_kernel(const double* __r
     __syncthreads();
   }
   for (int t = threadIdx.x; t < k; t += R64_THREADS) {
-    const bool in = t < have;
-    oidx[q * k + t] = in ? (int64_t)id[t] : -1;
-    oval[q * k + t] = in ? unmono_f64(key[t]) : -INFINITY;
+    const bool in = t < have && id[t] != 0xffffffffu;
+    oidx[q * ktotal + off + t] = in ? (int64_t)id[t] : -1;
+    oval[q * ktotal + off + t] = in ? unmono_f64(key[t]) : -INFINITY;
   }
 }
 
+constexpr int R64_PAGE = R64_CHUNK / 2;
+
 int launch_rank_f64(pvs_ctx* ctx, const double* scores, int64_t nq, int64_t ncols, int64_t ld, int k, int64_t* d_idx, double* d_val) {
   if (nq <= 0 || k <= 0) return PVS_OK;
-  if (k > R64_CHUNK / 2 && ncols > R64_CHUNK)
-    PVS_FAIL(PVS_ERR_UNSUPPORTED, "float64 ranking deeper than %d over more than %d columns is not supported", R64_CHUNK / 2, R64_CHUNK);
-  if (ncols >= ((int64_t)1 << 32)) PVS_FAIL(PVS_ERR_UNSUPPORTED, "float64 ranking: too many columns");
+  if (ncols >= ((int64_t)1 << 32) - 1) PVS_FAIL(PVS_ERR_UNSUPPORTED, "float64 ranking: too many columns");
   const size_t lds = (size_t)R64_CHUNK * 12;
   PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(rank_f64_kernel), lds));
   ScopedTimer tm(ctx, T_TOPK);
-  hipLaunchKernelGGL(rank_f64_kernel, dim3((unsigned)nq), dim3(R64_THREADS), lds, ctx->stream, scores, ncols, ld, k, d_idx, d_val);
+  if (k <= R64_PAGE || ncols <= R64_CHUNK) {
+    hipLaunchKernelGGL(rank_f64_kernel, dim3((unsigned)nq), dim3(R64_THREADS), lds, ctx->stream, scores, ncols, ld, k, k, 0, d_idx, d_val);
+  } else {
+    // deeper than one page over more columns than the LDS buffer holds: page through the complete rows
+    for (int off = 0; off < k; off += R64_PAGE)
+      hipLaunchKernelGGL(rank_f64_kernel, dim3((unsigned)nq), dim3(R64_THREADS), lds, ctx->stream, scores, ncols, ld,
+                         std::min(R64_PAGE, k - off), k, off, d_idx, d_val);
+  }
   PVS_HIP(hipGetLastError());
   return PVS_OK;
 }

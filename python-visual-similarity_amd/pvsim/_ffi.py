@@ -86,6 +86,9 @@ SIGNATURES = {
     "pvs_cosine_topk_f16_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _i64, _int, _vp, _vp],
     "pvs_cosine_topk": [_vp, _vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
     "pvs_cosine_topk_f64": [_vp, _vp, _i64, _vp, _i64, _i64, _int, _vp, _vp],
+    "pvs_row_inv_norms_f64_dev": [_vp, _vp, _i64, _i64, _vp],
+    "pvs_cosine_f64_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64],
+    "pvs_cosine_topk_f64_dev": [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp],
     "pvs_topk_merge_dev": [_vp, _vp, _vp, _int, _i64, _int, _vp, _vp],
     "pvs_materialise_dev": [_vp, _vp, _int, _int, _i64, _vp],
     "pvs_kmeans_step_dev": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],

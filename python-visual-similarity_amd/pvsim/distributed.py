@@ -125,6 +125,14 @@ class DevicePool:
     def full(self, shape, dtype: str, fill) -> DevArray:
         return self.empty(shape, dtype).fill(fill)
 
+    def release(self, arr: DevArray):
+        """Hand one array's block back (no-op if it is not a live block of this pool)."""
+        for i, (cls, buf) in enumerate(self._used):
+            if buf is arr._owner:
+                self._free.setdefault(cls, []).append(buf)
+                del self._used[i]
+                return
+
     def release_all(self):
         for cls, buf in self._used:
             self._free.setdefault(cls, []).append(buf)
@@ -171,7 +179,10 @@ def exchange_unique_id(rank: int, world: int, addr: str, port: int, timeout: flo
             with socket.create_connection((addr, port), timeout=5.0) as s:
                 head = b""
                 while len(head) < 4:
-                    head += s.recv(4 - len(head))
+                    chunk = s.recv(4 - len(head))
+                    if not chunk:                      # rank 0 closed early: retry until the deadline, never spin
+                        raise ConnectionError("short read (header)")
+                    head += chunk
                 n, = struct.unpack("<I", head)
                 data = b""
                 while len(data) < n:
@@ -238,7 +249,8 @@ class RcclComm:
     def close(self):
         if self.handle is not None:
             from . import _ffi
-            _ffi.lib().pvs_comm_destroy(self.handle)
+            if self.ctx.handle is not None:        # pvs_comm_destroy reads the context (device, stream): never after its close
+                _ffi.lib().pvs_comm_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -485,6 +497,9 @@ class ShardedVLADIndex:
         """d_desc / d_offsets: device pointers of this rank's packed descriptors and CSR offsets."""
         n_loc = self.hi - self.lo
         L = self.cb.K * self.cb.D
+        # a new encode starts a new cycle: the blocks of the previous encode / exchange / topk go back to the pool (same
+        # stream, so their reuse is ordered behind the work that still reads them) -- repeated cycles do not grow device memory
+        self.pool.release_all()
         self.enc_loc = self.pool.full((self.block, L), "float32", 0.0)
         self.inv_loc = self.pool.full((self.block,), "float32", 1.0)
         self.ctx.vlad_encode_dev(self.cb, d_desc, kind, d_offsets, n_loc, total_desc, self.enc_loc.ptr, power, norm_order,
@@ -502,8 +517,11 @@ class ShardedVLADIndex:
 
     def topk(self, k: int):
         n_loc = self.hi - self.lo
+        for b in getattr(self, "_lists", ()):          # the lists of the previous query on this index
+            self.pool.release(b)
         idx = self.pool.full((max(n_loc, 1), k), "int64", -1)
         val = self.pool.full((max(n_loc, 1), k), "float32", float("-inf"))
+        self._lists = (idx, val)
         retrieve_sharded(self.enc_loc, self.inv_loc, self.enc_all, self.inv_all, self.n_total, self.rank, self.world,
                          k, device_score_block(self.ctx), idx, val)
         self.ctx.sync()

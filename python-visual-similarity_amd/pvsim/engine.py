@@ -396,6 +396,18 @@ class Context:
         check(_ffi.lib().pvs_cosine_topk_f16_dev(self.handle, ptr(d_q), nq, ptr(d_db), N, L, ptr(d_invq), ptr(d_invdb), k,
                                                  col_offset, int(merge), ptr(d_idx), ptr(d_val)))
 
+    def row_inv_norms_f64_dev(self, d_x, rows, L, d_inv):
+        check(_ffi.lib().pvs_row_inv_norms_f64_dev(self.handle, ptr(d_x), rows, L, ptr(d_inv)))
+
+    def cosine_f64_dev(self, d_a, M, d_b, N, L, d_inva, d_invb, d_out, ldo):
+        """float64 operands and scores on the f64 matrix pipe (the reference's dtype for Fisher encodings)"""
+        check(_ffi.lib().pvs_cosine_f64_dev(self.handle, ptr(d_a), M, ptr(d_b), N, L, ptr(d_inva), ptr(d_invb), ptr(d_out), ldo))
+
+    def cosine_topk_f64_dev(self, d_q, nq, d_db, N, L, d_invq, d_invdb, k, d_idx, d_val):
+        """float64 scores + ranking, everything resident: d_idx int64 [nq][k], d_val float64 [nq][k]"""
+        check(_ffi.lib().pvs_cosine_topk_f64_dev(self.handle, ptr(d_q), nq, ptr(d_db), N, L, ptr(d_invq), ptr(d_invdb), int(k),
+                                                 ptr(d_idx), ptr(d_val)))
+
     def topk_merge_dev(self, d_idx_lists, d_val_lists, n_lists, nq, k, d_idx, d_val):
         check(_ffi.lib().pvs_topk_merge_dev(self.handle, ptr(d_idx_lists), ptr(d_val_lists), n_lists, nq, k, ptr(d_idx),
                                             ptr(d_val)))

@@ -75,3 +75,51 @@ def test_corpus1m_single_gpu_filtered_equals_exact():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["self_check"]["lists_bit_identical_to_plain_exact_ranking"] is True and line["n_gpus"] == 1
+
+
+def test_bench_starts_its_own_ranks_when_typed_without_a_launcher():
+    """Literally `python3 bench.py --gpus 2 ...` (the form the driver types): the parent never touches the GPU, starts the two
+    ranks as fresh processes through torch.distributed.run on 127.0.0.1 and relays rank 0's line.  With no workload flag the
+    N > 1 default is BASELINE configs[3]/[4] (1M-image corpus generator, fp16 exchange and retrieval, a bounded query block
+    shared out over the ranks); reduced here to 20000 images.  gloo REHEARSAL transport (two ranks on one GPU)."""
+    from conftest import REPO
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PVS_BENCH_BACKEND="gloo")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--images", "20000",
+                        "--total-queries", "4096"], env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "configs[3]/[4]" in line["config"]["workload"] and line["retrieval"] == "f16"
+    assert line["queries_per_step"] == 4096 and line["scaling"] == "strong"
+    assert line["self_check"]["fp16_recall_at_k_vs_exact_f32"] >= 0.99
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+
+
+def test_one_rank_rccl_point_to_point_and_collectives_without_torch():
+    """pvs_sendrecv_dev (the neighbour exchange's primitive), pvs_alltoall_dev, pvs_allgather_dev, pvs_allreduce_max_f64 on a
+    ONE-rank RCCL communicator behind the C-ABI, no torch in the process path: a self send / receive moves the bytes, a failing
+    call inside a group leaves the communicator usable."""
+    import numpy as np
+    import pvsim
+    from pvsim import distributed as pd
+    ctx = pvsim.Context(0)
+    comm = pd.RcclComm(ctx, 1, 0, pd.new_unique_id())
+    try:
+        src = np.arange(4096, dtype=np.float32)
+        a, b, c = ctx.buffer(src.nbytes).upload(src), ctx.buffer(src.nbytes).fill_bytes(0), ctx.buffer(src.nbytes).fill_bytes(0)
+        comm.send_recv([(0, a.ptr, src.nbytes, b.ptr, src.nbytes)])
+        comm.all_to_all(c.ptr, a.ptr, src.nbytes)
+        ctx.sync()
+        assert np.array_equal(b.download(src.shape, np.float32), src)
+        assert np.array_equal(c.download(src.shape, np.float32), src)
+        with pytest.raises(ValueError):
+            comm.send_recv([(3, a.ptr, 16, b.ptr, 16)])           # peer out of range: rejected before the group opens
+        d = ctx.buffer(src.nbytes).fill_bytes(0)
+        comm.all_gather(a.ptr, d.ptr, src.nbytes)                  # the communicator still works
+        assert comm.max_over_ranks([1.5, -2.0]).tolist() == [1.5, -2.0]
+        assert np.array_equal(d.download(src.shape, np.float32), src)
+    finally:
+        comm.close()
+        ctx.close()
+        comm.close()                                               # closing after the context is a no-op, not a use after free

@@ -106,10 +106,12 @@ def test_api_eval_functions_with_fisher_vectors(tables):
     assert abs(ev.top_k_map(wrapped, labels, emap, plab, fenc, None) - float(g["map_all"])) < 1e-12
 
 
-@pytest.mark.parametrize("nq,N,k", [(5, 10, 3), (3, 8189, 8189), (2, 20000, 4096), (4, 300, 300), (6, 9000, 1), (2, 8192, 100)])
+@pytest.mark.parametrize("nq,N,k", [(5, 10, 3), (3, 8189, 8189), (2, 20000, 4096), (4, 300, 300), (6, 9000, 1), (2, 8192, 100),
+                                    (2, 9000, 9000), (3, 20000, 5000), (1, 8193, 8193)])
 def test_float64_ranking_equals_a_stable_argsort(gpu_ctx, nq, N, k):
     """pvs_cosine_topk_f64: (score descending, index ascending) with NaN last, on rows with exact ties, -0 / +0, +-inf;
-    several LDS chunks when N > 8192."""
+    several LDS chunks when N > 8192; rankings deeper than 4096 over more than 8192 columns (top_k_map(k=None) on a Fisher
+    database: a full argsort in the reference, eval.py:78) page through the complete rows."""
     rng = np.random.default_rng(nq * 31 + N + k)
     L = 6
     db = rng.standard_normal((N, L))

@@ -1,0 +1,120 @@
+"""Round-3 GPU parity tests (through the C-ABI): the float64 similarity on the f64 matrix pipe and its device-resident entry
+points -- the reference's dtype rule for Fisher encodings (pyvisim/_utils.py:312-330: float32 only when BOTH operands are
+float32; eval.py:37-43 ranks that array)."""
+import numpy as np
+import pytest
+
+import pvsim_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_f64(ctx, a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return ctx.buffer(max(a.nbytes, 16)).upload(a)
+
+
+# shapes: one tile with edges / several tiles, general order / odd L (vector-ALU tile kernel) / a k-tile tail (L % 16 != 0) /
+# enough tiles for full rounds plus a split-K tail / L shorter than one k-tile
+@pytest.mark.parametrize("M,N,L", [(1, 7, 6), (130, 257, 1026), (64, 64, 15), (300, 129, 4100), (1200, 9000, 258), (5, 3, 2), (640, 8200, 64)])
+def test_f64_cosine_dev_against_numpy(gpu_ctx, M, N, L):
+    """pvs_cosine_f64_dev (v_mfma_f64_16x16x4_f64 when rows are 16-B aligned) = NumPy's float64 cosine to 1e-13."""
+    rng = np.random.default_rng(M * 7 + N * 3 + L)
+    a = rng.standard_normal((M, L)) * np.exp(rng.uniform(-3, 3, size=(M, 1)))
+    b = rng.standard_normal((N, L))
+    if N > 4:
+        b[3] = 0.0                                     # zero row: norm treated as 1, scores exactly 0
+    da, db = _dev_f64(gpu_ctx, a), _dev_f64(gpu_ctx, b)
+    ia, ib = gpu_ctx.buffer(M * 8), gpu_ctx.buffer(N * 8)
+    gpu_ctx.row_inv_norms_f64_dev(da.ptr, M, L, ia.ptr)
+    gpu_ctx.row_inv_norms_f64_dev(db.ptr, N, L, ib.ptr)
+    out = gpu_ctx.buffer(M * N * 8).fill_bytes(0xff)
+    gpu_ctx.cosine_f64_dev(da.ptr, M, db.ptr, N, L, ia.ptr, ib.ptr, out.ptr, N)
+    gpu_ctx.sync()
+    got = out.download((M, N), np.float64)
+    ref = orc.cosine_similarity(a, b)
+    assert ref.dtype == np.float64 and np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13)
+    if N > 4:
+        assert (got[:, 3] == 0).all()
+
+
+@pytest.mark.parametrize("N,L", [(300, 4098), (1000, 130), (2949, 64), (8189, 34)])
+def test_f64_self_similarity_is_bitwise_symmetric(gpu_ctx, N, L):
+    """A == B: only the upper triangle of 128 x 128 tiles is computed, the rest mirrored (and, for few tiles or a partly filled
+    last round, tiles are cut along k: 2949 rows = 24 x 24 tiles -> every tile split; 8189 rows -> 4 full rounds + a split tail).
+    out == out.T bit for bit, the diagonal is 1 to 1e-15, everything equals NumPy to 1e-13."""
+    rng = np.random.default_rng(N + L)
+    a = rng.standard_normal((N, L))
+    a[1::9] = a[0::9][: len(a[1::9])]                 # duplicated rows
+    da = _dev_f64(gpu_ctx, a)
+    ia = gpu_ctx.buffer(N * 8)
+    gpu_ctx.row_inv_norms_f64_dev(da.ptr, N, L, ia.ptr)
+    out = gpu_ctx.buffer(N * N * 8).fill_bytes(0xff)
+    gpu_ctx.cosine_f64_dev(da.ptr, N, da.ptr, N, L, ia.ptr, ia.ptr, out.ptr, N)
+    gpu_ctx.sync()
+    got = out.download((N, N), np.float64)
+    assert np.array_equal(got, got.T)
+    np.testing.assert_allclose(np.diag(got), 1.0, rtol=0, atol=4e-15)
+    rows = rng.choice(N, size=min(N, 64), replace=False)
+    np.testing.assert_allclose(got[rows], orc.cosine_similarity(a[rows], a), rtol=0, atol=1e-13)
+    # the host-pointer form of the same product (pvs_cosine, is_f64) goes through the same kernels
+    if N <= 1000:
+        np.testing.assert_array_equal(gpu_ctx.cosine(a, a), got)
+
+
+@pytest.mark.parametrize("nq,N,L,k", [(7, 500, 66, 5), (300, 300, 130, 300), (40, 9000, 18, 9000), (9000, 9000, 18, 3)])
+def test_f64_topk_dev_equals_host_form_and_stable_argsort(gpu_ctx, nq, N, L, k):
+    """pvs_cosine_topk_f64_dev (operands, norms, panels and lists resident) = pvs_cosine_topk_f64 (host pointers, one upload) =
+    a stable argsort of the device's own float64 scores; incl. Q == DB (symmetric kernel) and a full-depth ranking of 9000 rows."""
+    rng = np.random.default_rng(nq + N + L + k)
+    db = rng.standard_normal((N, L))
+    db[2::11] = db[0::11][: len(db[2::11])]
+    same = nq == N
+    q = db if same else rng.standard_normal((nq, L))
+    ddb = _dev_f64(gpu_ctx, db)
+    dq = ddb if same else _dev_f64(gpu_ctx, q)
+    idb = gpu_ctx.buffer(N * 8)
+    gpu_ctx.row_inv_norms_f64_dev(ddb.ptr, N, L, idb.ptr)
+    iq = idb if same else gpu_ctx.buffer(nq * 8)
+    if not same:
+        gpu_ctx.row_inv_norms_f64_dev(dq.ptr, nq, L, iq.ptr)
+    d_idx, d_val = gpu_ctx.buffer(nq * k * 8), gpu_ctx.buffer(nq * k * 8)
+    gpu_ctx.cosine_topk_f64_dev(dq.ptr, nq, ddb.ptr, N, L, iq.ptr, idb.ptr, k, d_idx.ptr, d_val.ptr)
+    gpu_ctx.sync()
+    idx, val = d_idx.download((nq, k), np.int64), d_val.download((nq, k), np.float64)
+    h_idx, h_val = gpu_ctx.cosine_topk_f64(q, db, k)
+    assert np.array_equal(idx, h_idx) and np.array_equal(val, h_val)
+    sub = slice(0, min(nq, 48))
+    full = gpu_ctx.cosine(q[sub], db) if not same else None
+    if full is None:                                   # the symmetric kernel's scores: take them from the device product itself
+        out = gpu_ctx.buffer(N * N * 8)
+        gpu_ctx.cosine_f64_dev(ddb.ptr, N, ddb.ptr, N, L, idb.ptr, idb.ptr, out.ptr, N)
+        gpu_ctx.sync()
+        full = out.download((N, N), np.float64)[sub]
+    np.testing.assert_allclose(full, orc.cosine_similarity(q[sub], db), rtol=0, atol=1e-13)
+    order = np.argsort(-full, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(idx[sub], order)
+    assert np.array_equal(val[sub], np.take_along_axis(full, order, 1))
+
+
+def test_top_k_map_full_depth_on_a_float64_database_larger_than_8192():
+    """eval.top_k_map(k=None) with float64 encodings and N > 8192 (used to raise NotImplementedError): the lists are the
+    oracle's full argsort wherever the oracle's scores are not tied within 1e-12."""
+    from pvsim import eval as pe
+    rng = np.random.default_rng(5)
+    N, L, nq = 8300, 24, 6
+    db = rng.standard_normal((N, L))
+    q = db[:nq] + 0.1 * rng.standard_normal((nq, L))
+    idx, val = pe._rank(q, db, None)
+    assert idx.shape == (nq, N) and val.dtype == np.float64
+    s = orc.cosine_similarity(q, db)
+    ref = np.argsort(-s, axis=1, kind="stable")
+    sv = np.take_along_axis(s, ref, 1)
+    np.testing.assert_allclose(val, sv, rtol=0, atol=1e-13)
+    clear = np.ones_like(ref, dtype=bool)
+    gap = np.abs(np.diff(sv, axis=1)) > 1e-12
+    clear[:, 1:] &= gap
+    clear[:, :-1] &= gap
+    assert np.array_equal(idx[clear], ref[clear])
+    assert (np.sort(idx, axis=1) == np.arange(N)).all()          # a permutation: every row ranked exactly once

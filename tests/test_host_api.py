@@ -18,9 +18,15 @@ def built():
 
 
 def _header_symbols():
-    text = open(os.path.join(REPO, "include", "pvsim.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pvs_[a-z0-9_]+)\s*\(", text)))
+    """every function declared in include/*.h: pvsim.h (the product ABI) and pvsim_diag.h (diagnostics)"""
+    syms = set()
+    for name in sorted(os.listdir(os.path.join(REPO, "include"))):
+        if not name.endswith(".h"):
+            continue
+        text = open(os.path.join(REPO, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(pvs_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
 
 
 def test_library_exports_every_header_symbol():
@@ -30,7 +36,7 @@ def test_library_exports_every_header_symbol():
     assert len(syms) >= 35
     lib = ctypes.CDLL(_ffi.LIB_PATH)
     for s in syms:
-        assert hasattr(lib, s), f"{s} declared in include/pvsim.h but not exported"
+        assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert sorted(_ffi.SIGNATURES) == syms            # the ctypes table binds exactly the header
     assert _ffi.lib().pvs_version() == 103
 
