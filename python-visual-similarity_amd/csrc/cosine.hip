@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "gemm_mfma.hpp"
 #include "gemm_f64.hpp"
+#include "gemm_f16_8ph.hpp"
 
 namespace pvs {
 
@@ -145,7 +146,16 @@ static int launch_gemm_mfma(pvs_ctx* ctx, GemmArgs g, const GemmPlan& plan) {
     PVS_TRY(ensure_lds(ctx, k, Cfg::LDS_BYTES));
   if (plan.n_main > 0) {
     g.tile_base = 0;
-    hipLaunchKernelGGL(kfull, dim3((unsigned)plan.n_main), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
+    if constexpr (MODEL == 1) {
+      // fp16 256 x 256: the full rounds run on the 8-phase schedule with v_mfma_f32_16x16x32_f16 (gemm_f16_8ph.hpp; measured
+      // 1.45 PFLOP/s against 1.12-1.19 for the two-stage kernel, profiles/r03_fp16_gemm_8phase_control_*.txt); the split-K
+      // tail of a partly filled last round stays on the two-stage kernel below (same tile list, same epilogue)
+      auto k8 = gemm_f16_8ph_kernel<SYMM, true>;
+      PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(k8), G8_LDS_BYTES));
+      hipLaunchKernelGGL(k8, dim3((unsigned)plan.n_main), dim3(512), G8_LDS_BYTES, ctx->stream, g);
+    } else {
+      hipLaunchKernelGGL(kfull, dim3((unsigned)plan.n_main), dim3(Cfg::THREADS), Cfg::LDS_BYTES, ctx->stream, g);
+    }
   }
   if (plan.n_tail > 0) {
     // partial images per tile: one per 1024-k chain (exact fp32 path) or one per slice (fp16 path)
@@ -232,7 +242,7 @@ int launch_cosine_f16(pvs_ctx* ctx, const void* A, int64_t M, const void* B, int
   if (M <= 0 || N <= 0) return PVS_OK;
   if (L <= 0 || L % 8 != 0 || reinterpret_cast<uintptr_t>(A) % 16 || reinterpret_cast<uintptr_t>(B) % 16)
     PVS_FAIL(PVS_ERR_UNSUPPORTED, "fp16 cosine needs 16-B aligned rows (L %% 8 == 0), got L = %lld", (long long)L);
-  if (L > (int64_t)16 * 1024 * 1024) PVS_FAIL(PVS_ERR_UNSUPPORTED, "fp16 cosine: L too large");
+  if (L > (int64_t)8 * 1024 * 1024) PVS_FAIL(PVS_ERR_UNSUPPORTED, "fp16 cosine: L too large");
   ScopedTimer tm(ctx, T_GEMM);
   return cosine_mfma<1>(ctx, A, M, B, N, L, inva, invb, out, ldo);
 }

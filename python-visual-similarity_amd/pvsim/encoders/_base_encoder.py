@@ -69,17 +69,23 @@ def _tupleize_first_arg(func: Callable) -> Callable:
 
 # ----------------------------------------------------------------------------------------- pretrained tables
 class _PretrainedModels(Enum):
-    """Same member names as the reference enums.  The reference stores joblib pickles of scikit-learn objects;
-    this engine stores plain arrays (`.npz`, see pvsim.models.save_model) and never unpickles anything.
-    Six of the reference's fourteen files are absent from its own checkout (all KMeans codebooks), so a
-    member only loads once its `.npz` has been placed in pvsim/res/model_files/."""
+    """Same member names as the reference enums (pyvisim/encoders/_base_encoder.py:117-155).  The reference stores joblib
+    pickles of scikit-learn objects; this engine stores plain arrays (`.npz`, pvsim.models.save_model) and never unpickles
+    anything.  The five GaussianMixture and three PCA tables the reference ships are here as arrays, read out of its files by
+    tests/golden/extract_reference_tables.py (an opcode walk that executes nothing).  The reference's KMeans files -- and its
+    VGG16 no-PCA mixture -- are absent from its own checkout: the KMeansWeights members load the float32 means_ of the
+    matching mixture as a stand-in codebook (with a warning), GMMWeights.OXFORD102_K256_VGG16 raises FileNotFoundError."""
 
     def load(self) -> object:
         if not os.path.exists(self.value):
             raise FileNotFoundError(
-                f"{self.value} not found. Convert a fitted model with pvsim.models.save_model(path, model) "
-                f"(plain arrays; the reference's .pkl files are joblib pickles and are not read).")
-        return _models.load_model(self.value)
+                f"{self.value} not found (the reference's checkout does not hold this model either). Convert a fitted model "
+                f"with pvsim.models.save_model(path, model): plain arrays, nothing is unpickled.")
+        m = _models.load_model(self.value)
+        if getattr(m, "derived_from", None):
+            warnings.warn(f"{self.name}: the reference's own KMeans file is absent from its checkout; this codebook is the "
+                          f"{m.derived_from}", stacklevel=2)
+        return m
 
 
 class KMeansWeights(_PretrainedModels):

@@ -55,7 +55,10 @@ def load_model(path: str):
     with np.load(path, allow_pickle=False) as z:
         kind = str(z["kind"])
         if kind == "kmeans":
-            return KMeansModel(z["cluster_centers"])
+            m = KMeansModel(z["cluster_centers"])
+            if "derived_from" in z.files:          # a stand-in codebook (see tests/golden/extract_reference_tables.py)
+                m.derived_from = str(z["derived_from"])
+            return m
         if kind == "gmm":
             return GMMModel(z["weights"], z["means"], z["covariances"])
         if kind == "pca":

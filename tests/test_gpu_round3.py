@@ -118,3 +118,53 @@ def test_top_k_map_full_depth_on_a_float64_database_larger_than_8192():
     clear[:, :-1] &= gap
     assert np.array_equal(idx[clear], ref[clear])
     assert (np.sort(idx, axis=1) == np.arange(N)).all()          # a permutation: every row ranked exactly once
+
+
+# ======================================================================================= the reference's shipped vocabularies
+def test_shipped_vocabularies_through_the_class_api():
+    """`FisherVectorEncoder(weights=GMMWeights.*)` / `VLADEncoder(weights=KMeansWeights.*)` as a pyvisim user writes them
+    (pyvisim/encoders/_base_encoder.py:117-155, 207-209), on the tables read out of the reference's own model files, against the
+    REFERENCE's outputs on those tables (tests/golden/shipped_tables.npz):
+      * OXFORD102_K256_ROOTSIFT: 487 covariance entries at the reg_covar floor (precision 1e6) -- the numerically hardest real
+        case (cancelling terms of ~1e6 in the log-density); 1e-9 abs on unit-norm float64 vectors;
+      * OXFORD102_K256_ROOTSIFT_PCA (128 -> 64) and OXFORD102_K256_VGG16_PCA (514 -> 257; FV length 131,840 as in
+        examples/pipeline.ipynb): the PCA member is paired automatically; fp32 projection, tolerance of its summation order;
+      * KMeansWeights.OXFORD102_K256_ROOTSIFT: the means_-derived stand-in codebook (warns): labels exact, values 5e-7."""
+    from shipped_inputs import shipped_inputs
+    from pvsim import synth
+    from pvsim.encoders import FisherVectorEncoder, VLADEncoder, GMMWeights, KMeansWeights
+    from pvsim.features import Lambda
+    from conftest import load_golden
+    g = load_golden("shipped_tables")
+    raws, deep = shipped_inputs()
+    imgs = [r.astype(np.float32) for r in raws]
+    rootsift_x = Lambda(synth.rootsift, 128)
+
+    f = FisherVectorEncoder(rootsift_x, weights=GMMWeights.OXFORD102_K256_ROOTSIFT)
+    assert f.pca is None and f.clustering_model.means_.shape == (256, 128)
+    F = f.encode(imgs)
+    assert F.dtype == np.float64 and F.shape == (5, 65792)
+    np.testing.assert_allclose(F[0], g["fisher_rootsift_img0"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(F[:, ::16], g["fisher_rootsift_every16"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(f.similarity_score(imgs, imgs), g["fisher_rootsift_cos"].astype(np.float32), rtol=0, atol=1e-6)
+
+    fp = FisherVectorEncoder(rootsift_x, weights=GMMWeights.OXFORD102_K256_ROOTSIFT_PCA)
+    assert fp.pca is not None and fp.pca.n_components == 64
+    Fp = fp.encode(imgs)
+    np.testing.assert_allclose(Fp[0], g["fisher_rootsift_pca_img0"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(Fp[:, ::16], g["fisher_rootsift_pca_every16"], rtol=0, atol=1e-7)
+
+    store = {i: d for i, d in enumerate(deep)}
+    fd = FisherVectorEncoder(Lambda(lambda im: store[int(im[0, 0])], 514), weights=GMMWeights.OXFORD102_K256_VGG16_PCA)
+    assert fd.pca.n_components == 257 and fd.pca.n_features_in_ == 514
+    Fd = fd.encode([np.array([[i]], dtype=np.int64) for i in range(len(deep))])
+    assert Fd.shape == (4, 131840)
+    np.testing.assert_allclose(Fd[0], g["fisher_vgg16_pca_img0"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(Fd[:, ::16], g["fisher_vgg16_pca_every16"], rtol=0, atol=2e-6)
+
+    with pytest.warns(UserWarning, match="absent from its checkout"):
+        v = VLADEncoder(rootsift_x, weights=KMeansWeights.OXFORD102_K256_ROOTSIFT)
+    V = v.encode(imgs)
+    np.testing.assert_allclose(V, g["vlad_rootsift"], rtol=0, atol=5e-7)
+    with pytest.raises(FileNotFoundError):
+        GMMWeights.OXFORD102_K256_VGG16.load()        # absent from the reference's checkout too (.MISSING_LARGE_BLOBS:2)

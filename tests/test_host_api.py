@@ -96,8 +96,15 @@ def test_constructor_validation_matches_reference():
     assert FisherVectorEncoder(_fx(8), gmm_model=gm).power_norm_weight == 0.5
     with pytest.raises(ValueError):
         Pipeline([ok, "not an encoder"])
-    with pytest.raises(FileNotFoundError):                 # absent pretrained tables are reported, not unpickled
-        KMeansWeights.OXFORD102_K256_ROOTSIFT.load()
+    with pytest.raises(FileNotFoundError):                 # a table the reference's checkout does not hold either is reported
+        GMMWeights.OXFORD102_K256_VGG16.load()
+    g = GMMWeights.OXFORD102_K256_ROOTSIFT.load()          # the reference's shipped tables, as plain arrays (never unpickled)
+    assert g.means_.shape == (256, 128) and g.means_.dtype == np.float64 and int((g.covariances_ < 1.01e-6).sum()) == 487
+    with pytest.warns(UserWarning, match="absent from its checkout"):     # KMeans files are missing upstream: derived stand-in
+        km2 = KMeansWeights.OXFORD102_K256_ROOTSIFT.load()
+    assert km2.cluster_centers_.shape == (256, 128) and km2.cluster_centers_.dtype == np.float32
+    from pvsim.encoders._base_encoder import _PCA
+    assert _PCA.OXFORD102_PCA256_VGG16.load().components_.shape == (257, 514)
     assert [m.name for m in KMeansWeights] == [m.name for m in GMMWeights]
     assert "VLADEncoder(feature_extractor=Lambda" in repr(ok)
 

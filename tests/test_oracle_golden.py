@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/pvsim_oracle.py) to golden vectors produced by the reference
 itself (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -280,3 +282,35 @@ def test_oracle_eval_with_fisher_vectors_ranks_in_float64(tables):
     assert orc.top_k_accuracy(fq, e["q_labels"], fdb, e["db_labels"], 5) == float(g["acc_k5"])
     assert abs(orc.top_k_map(fq, e["q_labels"], fdb, e["db_labels"], None) - float(g["map_all"])) < 1e-12
     assert abs(orc.top_k_map(fq, e["q_labels"], fdb, e["db_labels"], 5) - float(g["map_k5"])) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------- the reference's shipped tables
+def test_oracle_on_the_reference_shipped_tables():
+    """The restatement against the REFERENCE's encoders run on its OWN pretrained vocabularies (tests/golden/shipped_tables.npz,
+    made by make_golden_shipped.py from the arrays extract_reference_tables.py read out of the shipped files without unpickling
+    them): the RootSIFT mixture with 487 covariance entries at the reg_covar floor (precision 1e6), the PCA variants
+    (128 -> 64, 514 -> 257: FV length 131,840 as in examples/pipeline.ipynb), and VLAD on the means_-derived codebook."""
+    from shipped_inputs import shipped_inputs, MODELS
+    from pvsim import synth
+    g = load_golden("shipped_tables")
+    raws, deep = shipped_inputs()
+    imgs = [synth.rootsift(r.astype(np.float32)) for r in raws]
+    t = np.load(os.path.join(MODELS, "gmm_k256_root_sift_no_pca.npz"), allow_pickle=False)
+    assert int((t["covariances"] < 1.01e-6).sum()) == 487                 # SURVEY.md A.2
+    F = orc.fisher_encode(imgs, t["weights"], t["means"], t["covariances"])
+    np.testing.assert_allclose(F[0], g["fisher_rootsift_img0"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(F[:, ::16], g["fisher_rootsift_every16"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(orc.cosine_similarity(F, F), g["fisher_rootsift_cos"], rtol=0, atol=1e-12)
+    tp = np.load(os.path.join(MODELS, "gmm_k256_root_sift_pca.npz"), allow_pickle=False)
+    pp = np.load(os.path.join(MODELS, "pca_k256_root_sift_f2.npz"), allow_pickle=False)
+    Fp = orc.fisher_encode([orc.pca_transform(x, pp["components"], pp["mean"]) for x in imgs], tp["weights"], tp["means"], tp["covariances"])
+    np.testing.assert_allclose(Fp[:, ::16], g["fisher_rootsift_pca_every16"], rtol=0, atol=1e-7)     # fp32 projection: BLAS order
+    td = np.load(os.path.join(MODELS, "gmm_k256_deep_features_vgg16_pca.npz"), allow_pickle=False)
+    pd_ = np.load(os.path.join(MODELS, "pca_k256_deep_features_vgg16_f2.npz"), allow_pickle=False)
+    Fd = orc.fisher_encode([orc.pca_transform(x, pd_["components"], pd_["mean"]) for x in deep], td["weights"], td["means"], td["covariances"])
+    assert Fd.shape == (4, 131840)
+    np.testing.assert_allclose(Fd[:, ::16], g["fisher_vgg16_pca_every16"], rtol=0, atol=2e-6)        # 514-term fp32 projections
+    C = np.load(os.path.join(MODELS, "k_means_k256_root_sift_no_pca.npz"), allow_pickle=False)["cluster_centers"]
+    lab = np.concatenate([orc.kmeans_predict(x, C) for x in imgs])
+    assert np.array_equal(lab, g["vlad_labels"])
+    np.testing.assert_allclose(orc.vlad_encode(imgs, C), g["vlad_rootsift"], rtol=0, atol=2e-7)
