@@ -362,7 +362,7 @@ def side_workload(args):
                     "value": round(N / dt, 1), "unit": "rows/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "f16",
                     "scaling": "strong", "stages_ms_per_step": st,
                     "config": {"workload": f"{N} x {N} cosine, L = {L} fp16, fp32 accumulate, top-{k}"},
-                    "roofline": {"kernel": "gemm_mfma_kernel<256,256,f16>", "bound": "mfma",
+                    "roofline": {"kernel": "gemm_f16_8ph_kernel<256x256, v_mfma_f32_16x16x32_f16, 8-phase schedule>", "bound": "mfma",
                                  "achieved": round(flop / (st["cosine_gemm"] * 1e-3) / 1e12, 1), "peak": 2500.0,
                                  "unit": "TFLOP/s (algorithmic 2*N*N*L; panels on the diagonal run symmetric)",
                                  "frac": round(flop / (st["cosine_gemm"] * 1e-3) / 1e12 / 2500.0, 4), "traffic": None}})
@@ -764,8 +764,8 @@ def main():
         "config": {"workload": workload, "images": N, "descriptors_rank0": total_desc, "descriptor_rows": "u8" if corpus1m else args.desc,
                    "K": K_CLUSTERS, "D": DIM, "topk": k_top, "parallelism": f"image-sharded x{world}",
                    "encode_path": "fused one-read kernel" if args.fused else "assign + aggregate"},
-        "roofline": {"kernel": ("gemm_mfma_kernel<256,256,f16> (fp16 operands, fp32 accumulate)" if retr == "f16" else
-                                "gemm_mfma_kernel<128,128,f16, chains of 1024 k> (prefilter GEMM of the filtered retrieval)" if filtered else
+        "roofline": {"kernel": ("gemm_f16_8ph_kernel<256x256, 16x16x32> (fp16 operands, fp32 accumulate, 8-phase schedule)" if retr == "f16" else
+                                "gemm_f16_2lvl_kernel<256x128, chains of 1024 k> / gemm_mfma_kernel<128,128,f16,two-level> (prefilter GEMM of the filtered retrieval)" if filtered else
                                 "gemm_mfma_kernel<128,128,f32> (cosine GEMM: main + split-K tail)"), "bound": "mfma", "achieved": round(achieved, 2),
                      "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flop_per_launch,

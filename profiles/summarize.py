@@ -55,6 +55,29 @@ if path:
     for k, d in acc.items():
         if d.get("SQ_BUSY_CU_CYCLES"):
             out.setdefault(k, {})["mfma_pipe_busy_frac"] = round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * d["SQ_BUSY_CU_CYCLES"]), 4)
+# per-launch spread of every pvs kernel (kernel trace of the stats pass): min / median / max duration
+trace = one("stats/**/*_kernel_trace.csv")
+if trace:
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        if "pvs::" in r["Kernel_Name"]:
+            dur[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+    for k, v in dur.items():
+        v.sort()
+        out.setdefault(k, {})["launch_ms"] = {"n": len(v), "min": round(v[0], 4), "median": round(v[len(v) // 2], 4), "max": round(v[-1], 4),
+                                               "mean": round(sum(v) / len(v), 4)}
+# effective clock per kernel = GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time (MI355X guide, DVFS give-back; reads high below ~0.3 ms)
+path = one("grbm/**/*_counter_collection.csv")
+if path:
+    clk = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if "pvs::" in r["Kernel_Name"] and r.get("Counter_Name") == "GRBM_GUI_ACTIVE" and "End_Timestamp" in r:
+            ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if ns > 300000:
+                clk[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]) / 8.0 / ns)
+    for k, v in clk.items():
+        v.sort()
+        out.setdefault(k, {})["effective_clock_GHz"] = {"n": len(v), "min": round(v[0], 3), "median": round(v[len(v) // 2], 3), "max": round(v[-1], 3)}
 if out:
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES (separate passes) "
                           "--output-format csv -- python3 " + command,

@@ -14,6 +14,7 @@
 #define PVS_GEMM_DBG 1
 #include "../gemm_mfma.hpp"
 #include "../gemm_f16_8ph.hpp"
+#include "../gemm_f16_2lvl.hpp"
 
 using namespace pvs;
 
@@ -228,6 +229,65 @@ static float run8(const char* name, const void* A, const float* inv, int64_t N, 
   return sum / reps;
 }
 
+// the two-level 256 x 128 kernel (gemm_f16_2lvl.hpp): general tile order
+template <bool STAMP = false>
+static float run2(const char* name, const void* A, const float* inv, int64_t N, int64_t L, float* out, int ns,
+                  const double* ref_h, const int* sm_h, const int* sn_h, int reps = 3) {
+  GemmArgs g{};
+  g.A = A; g.B = A; g.M = N; g.N = N; g.L = L; g.lda = g_ld; g.ldb = g_ld; g.inva = inv; g.invb = inv; g.out = out;
+  g.ldo = N; g.splitk = 1;
+  CK(hipGetSymbolAddress((void**)&g.zero16, HIP_SYMBOL(d_zero16)));
+  std::vector<GemmTile> t = tile_list((int)((N + 255) / 256), (int)((N + 127) / 128), false);
+  GemmTile* d_t; CK(hipMalloc(&d_t, t.size() * sizeof(GemmTile)));
+  CK(hipMemcpy(d_t, t.data(), t.size() * sizeof(GemmTile), hipMemcpyHostToDevice));
+  g.tiles = d_t;
+  const int total = (int)t.size();
+  auto kf = gemm_f16_2lvl_kernel<STAMP>;
+  CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+  if (STAMP) CK(hipMalloc(&g.stamps, (size_t)total * 64));
+  auto launch = [&]() { hipLaunchKernelGGL(kf, dim3((unsigned)total), dim3(512), G2_LDS_BYTES, 0, g); };
+  CK(hipMemset(out, 0xff, (size_t)N * N * 4));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  launch();
+  CK(hipDeviceSynchronize());
+  float best = 1e30f, sum = 0.f;
+  for (int it = 0; it < reps; ++it) {
+    CK(hipEventRecord(e0));
+    launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    best = fminf(best, ms); sum += ms;
+  }
+  double maxerr = 0.0;
+  for (int s = 0; s < ns; ++s) {
+    float a, b;
+    CK(hipMemcpy(&a, out + (int64_t)sm_h[s] * N + sn_h[s], 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&b, out + (int64_t)sn_h[s] * N + sm_h[s], 4, hipMemcpyDeviceToHost));
+    maxerr = fmax(maxerr, fmax(fabs((double)a - ref_h[s]), fabs((double)b - ref_h[s])));
+  }
+  const double flop = 2.0 * 256 * 128 * (double)L * total;
+  printf("%-30s tiles %5d  avg %8.3f ms  best %8.3f  executed %7.2f TF/s  maxerr %.2e %s\n", name, total, sum / reps, best,
+         flop / (sum / reps * 1e-3) / 1e12, maxerr, maxerr < 2e-5 ? "ok" : "FAIL");
+  if (STAMP) {
+    std::vector<unsigned long long> h((size_t)total * 8);
+    CK(hipMemcpy(h.data(), g.stamps, (size_t)total * 64, hipMemcpyDeviceToHost));
+    std::vector<double> clk, cyc;
+    for (int b = 0; b < total; ++b) {
+      const double dt = (double)(h[8 * b + 1] - h[8 * b]), dr = (double)(h[8 * b + 3] - h[8 * b + 2]);
+      if (dr > 0) { clk.push_back(dt / dr * 0.1); cyc.push_back(dt); }
+    }
+    std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
+    printf("   [stamped build] in-kernel clock %.3f GHz (median over workgroups); k-loop %.1f cycles per k-tile (MFMA floor 512 per wave, 1024 per SIMD)\n",
+           clk[clk.size() / 2], cyc[cyc.size() / 2] / (double)((L + 63) / 64));
+    CK(hipFree(g.stamps));
+  }
+  fflush(stdout);
+  CK(hipFree(d_t));
+  return sum / reps;
+}
+
 // Which scalar recurrence reproduces the f32 MFMA accumulation bit for bit?  (needed by an exact re-scoring kernel)
 static void chain_check(const float* A, const float* inv, const float* out, int64_t N, int64_t L, const int* sm, const int* sn, int ns) {
   std::vector<float> ra(L), rb(L);
@@ -351,6 +411,20 @@ int main(int argc, char** argv) {
     run8<false, true, true>("f16 8-phase 16x16x32 stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
     run8<false, false, true>("f16 8-phase 32x32x16 stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
     run<256, 256, 2, 4, 2, false, 2, true, true, false, true>("f16 256x256 shipped stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
+  }
+  if (which == 4) {   // the two-level (chains of 1024 k) prefilter GEMM: 128 x 128 two-stage kernel vs the 256 x 128 phase-scheduled one
+    _Float16* A16; CK(hipMalloc(&A16, (size_t)N * g_ld * 2));
+    hipLaunchKernelGGL(to_half, dim3((unsigned)(((int64_t)N * g_ld + 255) / 256)), dim3(256), 0, 0, A, A16, N * g_ld);
+    hipLaunchKernelGGL(ref_samples_h, dim3(ns), dim3(64), 0, 0, A16, inv, L, g_ld, d_sm, d_sn, ns, d_ref);
+    std::vector<double> refh(ns);
+    CK(hipMemcpy(refh.data(), d_ref, ns * 8, hipMemcpyDeviceToHost));
+    const int rounds = argc > 5 ? atoi(argv[5]) : 3;
+    for (int round = 0; round < rounds; ++round) {
+      run<128, 128, 2, 2, 2, false, 2, false, true, true, false>("f16 128x128 two-level (shipped)", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
+      run2<false>("f16 256x128 two-level phases", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
+      run8<false, true>("f16 8-phase 16x16x32 (1 level)", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
+    }
+    run2<true>("f16 256x128 two-level stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
   }
   return 0;
 }

@@ -71,7 +71,7 @@ struct pvs_ctx {
     int n_main = 0, n_tail = 0, splitk = 1;
     void* d_tiles = nullptr;
     size_t cap = 0;
-  } gemm_plan[4];   // 0 exact fp32, 1 fp16 256x256, 2 fp16 128x128 two-level, 3 float64
+  } gemm_plan[5];   // 0 exact fp32, 1 fp16 256x256, 2 fp16 128x128 two-level, 3 float64, 4 fp16 256x128 two-level
   // dynamic-LDS limits already raised on this context's device: kernel -> bytes
   std::map<const void*, int> lds_attr;
   // behaviour switches (pvs_set_option); defaults = the product path

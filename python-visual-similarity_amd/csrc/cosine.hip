@@ -16,6 +16,7 @@
 #include "gemm_mfma.hpp"
 #include "gemm_f64.hpp"
 #include "gemm_f16_8ph.hpp"
+#include "gemm_f16_2lvl.hpp"
 
 namespace pvs {
 
@@ -193,6 +194,26 @@ static int cosine_mfma(pvs_ctx* ctx, const void* A, int64_t M, const void* B, in
   // self-similarity: same operand, same norms -> only the upper triangle is computed, the rest mirrored
   const bool symm = (A == B) && (M == N) && (inva == invb) && out_t == nullptr;
   GemmPlan* plan = nullptr;
+  if constexpr (MODEL == 2) {
+    // the bounded-error prefilter on problems of several full rounds of 256 x 128 tiles (a query block against a corpus
+    // panel): gemm_f16_2lvl.hpp, 1.13 against 0.93 PFLOP/s (profiles/r03_fp16_gemm_two_level_256x128.txt); whole tiles only, so
+    // small problems and the symmetric case keep the 128 x 128 kernel with its split-K tail
+    const int t256 = (int)((M + 255) / 256), t128 = (int)((N + 127) / 128);
+    if (!symm && out_t == nullptr && (int64_t)t256 * t128 >= (int64_t)4 * ctx->num_cu && (int64_t)t256 * t128 <= 0x3fffffffLL &&
+        L <= (int64_t)8 * 1024 * 1024) {
+      PVS_TRY(build_plan(ctx, 4, t256, t128, false, ctx->num_cu, &plan));
+      GemmArgs g{};
+      g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = ld ? ld : L; g.ldb = ld ? ld : L; g.inva = inva; g.invb = invb;
+      g.accumulate = accumulate;
+      g.out = out; g.ldo = ldo; g.tiles = static_cast<const GemmTile*>(plan->d_tiles); g.splitk = 1; g.tile_base = 0;
+      PVS_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(const_cast<float**>(&g.zero16)), HIP_SYMBOL(g_zero16)));
+      auto k2 = gemm_f16_2lvl_kernel<false>;
+      PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(k2), G2_LDS_BYTES));
+      hipLaunchKernelGGL(k2, dim3((unsigned)(plan->n_main + plan->n_tail)), dim3(512), G2_LDS_BYTES, ctx->stream, g);
+      PVS_HIP(hipGetLastError());
+      return PVS_OK;
+    }
+  }
   PVS_TRY(build_plan(ctx, MODEL, tiles_m, tiles_n, symm, ctx->num_cu * GemmModel<MODEL>::PER_CU, &plan));
   GemmArgs g{};
   g.A = A; g.B = B; g.M = M; g.N = N; g.L = L; g.lda = ld ? ld : L; g.ldb = ld ? ld : L; g.inva = inva; g.invb = invb;

@@ -337,7 +337,10 @@ __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostM
     const int k = wn * 64 + 16 * ni + col;
     cst[ni] = k < a.K ? a.cst[k] : -INFINITY;
   }
-  double mx[4][4];
+  // (no per-lane copy of the 16 row maxima is kept across the phases: 32 registers that pushed the kernel over 256 and into
+  // scratch -- the one kernel of the EM chain with a private segment; the maxima are re-read from LDS where they are used)
+  double (*red2)[4] = reinterpret_cast<double (*)[4]>(reinterpret_cast<double*>(red) + PM_ROWS * 4);   // [PM_ROWS][4] partial sums
+  double* const rmax = reinterpret_cast<double*>(red2) + PM_ROWS * 4;                                  // [PM_ROWS] row maxima
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -352,28 +355,25 @@ __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostM
       if (col == 0) red[wm * 64 + 16 * mi + 4 * r + rq][wn] = m;
     }
   __syncthreads();
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = wm * 64 + 16 * mi + 4 * r + rq;
-      mx[mi][r] = fmax(fmax(red[row][0], red[row][1]), fmax(red[row][2], red[row][3]));
-    }
-  __syncthreads();
   // e = exp(logp - max) is formed once and kept in the accumulators; gamma = e / sum (within 2 ulp of scipy's
   // exp(logp - logsumexp)); the row's log-sum-exp itself is only needed by training
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      const int row = wm * 64 + 16 * mi + 4 * r + rq;
+      const double m = fmax(fmax(red[row][0], red[row][1]), fmax(red[row][2], red[row][3]));
       double s = 0.0;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
-        acc[mi][ni][r] = exp(acc[mi][ni][r] - mx[mi][r]);
+        acc[mi][ni][r] = exp(acc[mi][ni][r] - m);
         s += acc[mi][ni][r];
       }
       for (int q = 8; q >= 1; q >>= 1) s += __shfl_xor(s, q, 64);
-      if (col == 0) red[wm * 64 + 16 * mi + 4 * r + rq][wn] = s;
+      if (col == 0) {
+        red2[row][wn] = s;
+        if (wn == 0) rmax[row] = m;
+      }
     }
   __syncthreads();
 #pragma unroll
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostM
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wm * 64 + 16 * mi + 4 * r + rq;
-      const double sum = ((red[row][0] + red[row][1]) + red[row][2]) + red[row][3];
+      const double sum = ((red2[row][0] + red2[row][1]) + red2[row][2]) + red2[row][3];
       const double rs = 1.0 / sum;
       if (r0 + row < a.total) {
 #pragma unroll
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostM
           const int k = wn * 64 + 16 * ni + col;
           if (k < a.K) a.resp[(r0 + row) * a.K + k] = acc[mi][ni][r] * rs;
         }
-        if (a.lse != nullptr && wn == 0 && col == 0) a.lse[r0 + row] = mx[mi][r] + log(sum);
+        if (a.lse != nullptr && wn == 0 && col == 0) a.lse[r0 + row] = rmax[row] + log(sum);
       }
     }
 }
@@ -819,7 +819,7 @@ static int posterior_mfma_on(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int
   hipLaunchKernelGGL(build_tab2_kernel, dim3((unsigned)((kd + 255) / 256)), dim3(256), 0, ctx->stream, g->d_prec, g->d_mup,
                      g->K, g->D, tab2);
   PostMArgs a{x, total, g->D, ld, g->K, tab2, g->d_const, d_resp, d_lse};
-  constexpr size_t lds = (size_t)(2 * PM_ROWS * F64_KCP + 2 * PM_COLS * F64_KCP + PM_ROWS * 4) * sizeof(double);
+  constexpr size_t lds = (size_t)(2 * PM_ROWS * F64_KCP + 2 * PM_COLS * F64_KCP + PM_ROWS * 4 + PM_ROWS * 4 + PM_ROWS) * sizeof(double);   // operands | row maxima per wave column | partial sums | row maxima
   PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(gmm_posterior_mfma_kernel), lds));
   ScopedTimer tm(ctx, T_FPOST);
   hipLaunchKernelGGL(gmm_posterior_mfma_kernel, dim3((unsigned)((total + PM_ROWS - 1) / PM_ROWS)), dim3(PM_THREADS), lds, ctx->stream, a);

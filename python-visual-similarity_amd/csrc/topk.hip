@@ -270,13 +270,202 @@ __global__ __launch_bounds__(TK_THREADS) void topk_small_kernel(TopkArgs a) {
   }
 }
 
+// Small k (<= 16), panels of many columns: THRESHOLD FILTER in front of the ranking, ONE WAVE PER ROW (no workgroup barrier).
+// Once k keys are known to exist, their k-th best score T is a lower bound of the final k-th best, so a column can only
+// matter if its score is >= T (ties included: the 64-bit key decides among equal scores).  A chunk of 2048 columns is 32
+// values per lane: one compare each, the few survivors are compacted (ballot + prefix count) into the wave's candidate list
+// in LDS, and that list is ranked once at the end -- a bitonic sort across the 64 lanes, registers only.  T comes from the
+// running list of the previous panels (its k-th entry) or, on a row's first chunk, from the chunk itself: the k-th largest
+// of the 64 lane maxima is reached by k columns.  Rows whose scores are so tied that the survivors do not fit the list (an
+// all-zero query) fall back to k rounds of "best remaining key" over the chunk.  Same keys, same total order as the two
+// kernels above: the lists are theirs, bit for bit.  The rounds kernel is instruction-bound on 8192 x 32768 panels (1.2 ms per
+// GB); this one streams the panel.
+constexpr int TKW_WAVES = 4;                 // rows per workgroup
+constexpr int TKW_LIST = 256;                // candidate list capacity per wave (keys)
+constexpr int TKW_CHUNK = 64 * TK_ITEMS;     // 2048 columns
+
+// descending bitonic sort across the 64 lanes of a wave (registers only): lane i ends up with the i-th largest value
+template <typename T>
+__device__ __forceinline__ T wave_sort_desc(T v, int lane) {
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const T o = __shfl_xor(v, stride, 64);
+      const bool keep_max = ((lane & stride) == 0) == ((lane & size) == 0);
+      v = keep_max ? (o > v ? o : v) : (o < v ? o : v);
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+  for (int m = 32; m >= 1; m >>= 1) {
+    const uint64_t o = __shfl_xor(v, m, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// VEC: rows are 16-B aligned (ld % 4 == 0): 16-B loads, lane l holds columns c0 + 4 (64 j + l) + e, j = 0..7, e = 0..3
+template <bool VEC>
+__global__ __launch_bounds__(64 * TKW_WAVES) void topk_wave_kernel(TopkArgs a) {
+  __shared__ uint64_t cand_all[TKW_WAVES][TKW_LIST];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * TKW_WAVES + wave;
+  if (q >= a.nq) return;                     // whole waves leave: nothing below synchronises across waves
+  uint64_t* const cand = cand_all[wave];
+  const int k = a.k;
+  int64_t* const oidx = a.idx + q * a.out_ld;
+  float* const oval = a.val + q * a.out_ld;
+  const float* const row = a.scores + q * a.ld;
+
+  // the list: cand[0..n), unsorted; T = a score (order-preserving 32-bit image) that at least k known keys reach, 0 = none yet
+  int n = 0;
+  uint32_t T = 0u;
+  if (a.merge) {
+    const uint64_t key = (lane < k && oidx[lane] >= 0) ? make_key(oval[lane], (uint32_t)oidx[lane]) : 0ull;
+    const unsigned long long bm = __ballot(key != 0ull);
+    if (key != 0ull) cand[__popcll(bm & ((1ull << lane) - 1ull))] = key;
+    n = __popcll(bm);
+    if (oidx[k - 1] >= 0) T = mono_f32(oval[k - 1]);   // the running list is sorted: its last entry is the k-th best so far
+  }
+  // list (n <= TKW_LIST) -> its best min(n, k) keys in cand[0..), sorted; tightens T
+  auto list_topk = [&]() {
+    uint64_t key[TKW_LIST / 64];
+#pragma unroll
+    for (int it = 0; it < TKW_LIST / 64; ++it) key[it] = (it * 64 + lane) < n ? cand[it * 64 + lane] : 0ull;
+    uint64_t keep = 0ull;                    // lane r keeps the r-th winner
+    for (int r = 0; r < k; ++r) {
+      uint64_t mine = 0ull;
+#pragma unroll
+      for (int it = 0; it < TKW_LIST / 64; ++it) mine = key[it] > mine ? key[it] : mine;
+      const uint64_t b = wave_max_u64(mine);
+      if (lane == r) keep = b;
+      if (b != 0ull && mine == b) {
+#pragma unroll
+        for (int it = 0; it < TKW_LIST / 64; ++it) key[it] = key[it] == b ? 0ull : key[it];
+      }
+    }
+    if (lane < k) cand[lane] = keep;
+    n = n < k ? n : k;
+    if (n == k) T = (uint32_t)(__shfl(keep, k - 1, 64) >> 32);
+  };
+
+  for (int64_t c0 = 0; c0 < a.ncols; c0 += TKW_CHUNK) {
+    uint32_t m[TK_ITEMS];     // order-preserving images of this lane's 32 scores (0 = no column)
+    auto col = [&](int it) -> int64_t {      // column of element `it` (increasing in `it` for both layouts)
+      return VEC ? c0 + ((int64_t)(it >> 2) * 64 + lane) * 4 + (it & 3) : c0 + (int64_t)it * 64 + lane;
+    };
+    if constexpr (VEC) {
+#pragma unroll
+      for (int j = 0; j < TK_ITEMS / 4; ++j) {
+        const int64_t c = c0 + ((int64_t)j * 64 + lane) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c + 3 < a.ncols) v = *reinterpret_cast<const float4*>(row + c);
+        else {
+          if (c + 0 < a.ncols) v.x = row[c + 0];
+          if (c + 1 < a.ncols) v.y = row[c + 1];
+          if (c + 2 < a.ncols) v.z = row[c + 2];
+        }
+        m[4 * j + 0] = c + 0 < a.ncols ? mono_f32(v.x) : 0u;
+        m[4 * j + 1] = c + 1 < a.ncols ? mono_f32(v.y) : 0u;
+        m[4 * j + 2] = c + 2 < a.ncols ? mono_f32(v.z) : 0u;
+        m[4 * j + 3] = c + 3 < a.ncols ? mono_f32(v.w) : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < TK_ITEMS; ++it) {
+        const int64_t c = col(it);
+        m[it] = c < a.ncols ? mono_f32(row[c]) : 0u;
+      }
+    }
+    if (T == 0u) {
+      // no threshold yet: the k-th largest of the 64 lane maxima is reached by k columns of this chunk (0: fewer than k columns)
+      uint32_t mx = 0u;
+#pragma unroll
+      for (int it = 0; it < TK_ITEMS; ++it) mx = m[it] > mx ? m[it] : mx;
+      T = __shfl(wave_sort_desc(mx, lane), k - 1, 64);
+    }
+    const uint32_t thr = T == 0u ? 1u : T;
+    const int n0 = n;
+    bool overflow = false;
+#pragma unroll
+    for (int it = 0; it < TK_ITEMS; ++it) {
+      const bool pass = m[it] >= thr;
+      const unsigned long long bm = __ballot(pass);
+      if (bm != 0ull) {                      // wave-uniform
+        const int cnt = __popcll(bm);
+        if (n + cnt <= TKW_LIST) {
+          if (pass) cand[n + __popcll(bm & ((1ull << lane) - 1ull))] = ((uint64_t)m[it] << 32) | (uint64_t)(~(uint32_t)(a.col_offset + col(it)));
+        } else {
+          overflow = true;
+        }
+        n += cnt;
+      }
+    }
+    if (!overflow) {
+      if (n > TKW_LIST / 2) list_topk();
+      continue;
+    }
+    // too many survivors (heavily tied scores): drop this chunk's appends, keep the best k of the list, then k rounds of "best
+    // remaining key" over the chunk's survivors and that list.  A lane's best is its largest score, the first (lowest column)
+    // among equal ones.
+    n = n0;
+    list_topk();
+    uint64_t lk = lane < n ? cand[lane] : 0ull;
+    uint64_t keep = 0ull;
+    for (int r = 0; r < k; ++r) {
+      uint32_t mx = 0u;
+      int at = -1;
+#pragma unroll
+      for (int it = 0; it < TK_ITEMS; ++it)
+        if (m[it] >= thr && m[it] > mx) { mx = m[it]; at = it; }
+      uint64_t mine = at >= 0 ? ((uint64_t)mx << 32) | (uint64_t)(~(uint32_t)(a.col_offset + col(at))) : 0ull;
+      const bool from_list = lk > mine;
+      mine = from_list ? lk : mine;
+      const uint64_t b = wave_max_u64(mine);
+      if (lane == r) keep = b;
+      if (b != 0ull && mine == b) {
+        if (from_list) lk = 0ull;
+        else {
+#pragma unroll
+          for (int it = 0; it < TK_ITEMS; ++it) m[it] = it == at ? 0u : m[it];
+        }
+      }
+    }
+    if (lane < k) cand[lane] = keep;
+    n = __popcll(__ballot(lane < k && keep != 0ull));
+    if (n == k) T = (uint32_t)(__shfl(keep, k - 1, 64) >> 32);
+  }
+  // ---- rank the list: <= 64 keys by a bitonic sort across the lanes
+  if (n > 64) list_topk();
+  const uint64_t kk = wave_sort_desc(lane < n ? cand[lane] : 0ull, lane);
+  if (lane < k) {
+    if (kk != 0ull) {
+      oidx[lane] = (int64_t)(~(uint32_t)kk);
+      oval[lane] = unmono_f32((uint32_t)(kk >> 32));
+    } else {
+      oidx[lane] = -1;
+      oval[lane] = -INFINITY;
+    }
+  }
+}
+
 static int launch_topk_impl(pvs_ctx* ctx, const TopkArgs& a) {
   if (a.nq <= 0) return PVS_OK;
   if (a.k < 1 || a.k > TK_KMAX) PVS_FAIL(PVS_ERR_UNSUPPORTED, "top-k: k must be in [1, %d] (got %d)", TK_KMAX, a.k);
   if (a.nq > 0x7fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "top-k: too many query rows for one launch");
   if (a.col_offset + a.ncols > 0xfffffffeLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "top-k: column index exceeds 32 bits");
   ScopedTimer tm(ctx, T_TOPK);
-  if (a.k <= TKS_KMAX && a.n_lists == 0 && a.out_off == 0 && a.out_ld == a.k && !ctx->opt[PVS_OPT_TOPK_SELECT_ONLY])
+  const int variant = ctx->opt[PVS_OPT_TOPK_SELECT_ONLY];   // 0 chosen here, 1 radix select, 2 rounds, 3 threshold filter + rounds
+  const bool small = a.k <= TKS_KMAX && a.n_lists == 0 && a.out_off == 0 && a.out_ld == a.k && variant != 1;
+  if (small && (variant == 3 || (variant == 0 && a.ncols >= 2 * TK_CHUNK))) {
+    const bool vec = a.ld % 4 == 0 && reinterpret_cast<uintptr_t>(a.scores) % 16 == 0;
+    const unsigned grid = (unsigned)((a.nq + TKW_WAVES - 1) / TKW_WAVES);
+    if (vec) hipLaunchKernelGGL(topk_wave_kernel<true>, dim3(grid), dim3(64 * TKW_WAVES), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(topk_wave_kernel<false>, dim3(grid), dim3(64 * TKW_WAVES), 0, ctx->stream, a);
+  }
+  else if (small)
     hipLaunchKernelGGL(topk_small_kernel, dim3((unsigned)a.nq), dim3(TK_THREADS), 0, ctx->stream, a);
   else
     hipLaunchKernelGGL(topk_kernel, dim3((unsigned)a.nq), dim3(TK_THREADS), 0, ctx->stream, a);

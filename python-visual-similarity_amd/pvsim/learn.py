@@ -98,6 +98,20 @@ def _rng(random_state):
     raise ValueError(f"{random_state!r} cannot be used to seed a numpy.random.RandomState instance")
 
 
+def _one_blas_thread():
+    """Context for the host's small dense algebra (a D x D eigen-decomposition): ONE BLAS / LAPACK thread.  A library pool of
+    dozens of threads keeps spinning after such a call; inside a CPU-quota cgroup (the GPU boxes give a 256-CPU host 16 CPUs'
+    worth) that burns the quota and the kernel throttles the whole process for the rest of its 100-ms period -- measured as an
+    ~80-ms stall somewhere in the NEXT fit's launch chain (tests/tools/gap_trace.py: the host stops issuing HIP calls, once a
+    hipLaunchKernel itself took 71 ms).  threadpoolctl is optional: without it the call runs as the library is configured."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=1)
+    except Exception:
+        import contextlib
+        return contextlib.nullcontext()
+
+
 # ------------------------------------------------------------------------------------------------ PCA
 def fit_pca(rows: DeviceRows, n_components: int) -> PCAModel:
     """PCA.fit with the "covariance_eigh" solver (sklearn/decomposition/_pca.py:_fit_full, the solver "auto" picks for
@@ -111,7 +125,8 @@ def fit_pca(rows: DeviceRows, n_components: int) -> PCAModel:
     s, g = rows.ctx.gram_dev(rows.ptr, D, n)
     mean = s / n
     cov = (g - n * np.outer(mean, mean)) / (n - 1)
-    vals, vecs = np.linalg.eigh(cov)
+    with _one_blas_thread():
+        vals, vecs = np.linalg.eigh(cov)
     vals, vecs = vals[::-1].copy(), vecs[:, ::-1]
     vals[vals < 0.0] = 0.0
     vt = vecs.T.copy()

@@ -995,7 +995,7 @@ def test_learn_gmm_more_than_256_components(gpu_ctx):
     rows.free()
 
 
-@pytest.mark.parametrize("nq,N,k", [(9, 8189, 5), (4, 300, 16), (3, 20000, 1), (6, 7, 10), (5, 40000, 8)])
+@pytest.mark.parametrize("nq,N,k", [(9, 8189, 5), (4, 300, 16), (3, 20000, 1), (6, 7, 10), (5, 40000, 8), (7, 70000, 10), (3, 16384, 16)])
 def test_small_k_kernel_equals_the_radix_select(gpu_ctx, nq, N, k, monkeypatch):
     """k <= 16 takes the extraction kernel: same keys, same order as the radix select -- ties, NaN, -0.0, -inf, fewer columns
     than k, several 8192-column chunks and the running-list merge included."""
@@ -1011,7 +1011,7 @@ def test_small_k_kernel_equals_the_radix_select(gpu_ctx, nq, N, k, monkeypatch):
     s[2, :] = -np.inf
     panels = [(0, N // 2), (N // 2, N)] if N > 20 else [(0, N)]
     out = []
-    for select_only in (True, False):
+    for select_only in (1, 2, 3, 0):       # radix select, k rounds, threshold filter + rounds, the launcher's own choice
         gpu_ctx.set_option(_ffi.OPT_TOPK_SELECT_ONLY, int(select_only))
         idx = torch.full((nq, k), -9, dtype=torch.int64, device=dev)
         val = torch.full((nq, k), -9.0, dtype=torch.float32, device=dev)
@@ -1022,8 +1022,9 @@ def test_small_k_kernel_equals_the_radix_select(gpu_ctx, nq, N, k, monkeypatch):
             gpu_ctx.sync()
         out.append((idx.cpu().numpy(), val.cpu().numpy()))
     gpu_ctx.set_option(_ffi.OPT_TOPK_SELECT_ONLY, 0)
-    assert np.array_equal(out[0][0], out[1][0])
-    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0])
+        assert np.array_equal(out[0][1].view(np.uint32), o[1].view(np.uint32))
 
 
 def test_u8_rootsift_short_sequence_equals_ieee(gpu_ctx):
