@@ -602,7 +602,21 @@ def main():
 
     def retrieve(filtered_now):
         exchanged = exchange_begin() if multi else (lambda: None)
-        if retr == "f16":
+        if retr == "f16" and multi and n_loc > 0:
+            # the rank's own block first, from its local copy, while the other blocks are still arriving; then the rows before
+            # and after it in the gathered corpus, merged into the same lists (rows [0, N) of the gathered array are the real
+            # ones: every block but the last is full)
+            e16 = enc16_all.element_size() * L
+            ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_loc.data_ptr(), n_loc, L, inv_loc.data_ptr(), inv_loc.data_ptr(), k_top,
+                                    lo, False, idx.data_ptr(), val.data_ptr())
+            exchanged()
+            if lo > 0:
+                ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_all.data_ptr(), lo, L, inv_loc.data_ptr(), inv_all.data_ptr(), k_top,
+                                        0, True, idx.data_ptr(), val.data_ptr())
+            if hi < N:
+                ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_all.data_ptr() + hi * e16, N - hi, L, inv_loc.data_ptr(),
+                                        inv_all.data_ptr() + hi * 4, k_top, hi, True, idx.data_ptr(), val.data_ptr())
+        elif retr == "f16":
             exchanged()
             ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_all.data_ptr(), N, L, inv_loc.data_ptr(), inv_all.data_ptr(), k_top,
                                     0, False, idx.data_ptr(), val.data_ptr())
@@ -755,7 +769,7 @@ def main():
         "metric": "images/sec encoded + top-k retrieved, VLAD K256 RootSIFT",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         **({"exchange": "allgather over " + ("gloo (host-staged REHEARSAL)" if staged else "RCCL behind the C-ABI (" + pd.RcclComm.library() + ")"),
-            "exchange_overlaps_own_block": bool(overlap and not staged and retr == "exact")} if multi else {}),
+            "exchange_overlaps_own_block": bool(overlap and not staged and retr in ("exact", "f16"))} if multi else {}),
         **({"backend": "ONE-rank RCCL self-check of the multi-rank path: not a measurement"} if forced else {}),
         **({"backend": "gloo REHEARSAL (ranks share GPUs, host-staged collectives): not a measurement"} if staged else {}),
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

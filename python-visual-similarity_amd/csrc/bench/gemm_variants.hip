@@ -65,6 +65,20 @@ __global__ void ref_samples_h(const _Float16* x, const float* inv, int64_t L, in
   if (lane == 0) out[s] = acc * (double)inv[sm[s]] * (double)inv[sn[s]];
 }
 
+// [row block of 128][k-tile][128 rows x 64 halfs, 16-B chunk g of row r at chunk g ^ ((r >> 1) & 7)], zero padded
+__global__ void to_tiled(const _Float16* x, int64_t rows, int64_t L, int64_t ld, _Float16* t, int64_t nk) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-B chunk of the tiled array per thread
+  const int64_t nchunks = ((rows + 127) / 128) * nk * 128 * 8;
+  if (i >= nchunks) return;
+  const int p = (int)(i & 7), rr = (int)((i >> 3) & 127);
+  const int64_t bt = i >> 10, kt = bt % nk, blk = bt / nk;
+  const int g = p ^ ((rr >> 1) & 7);
+  const int64_t r = blk * 128 + rr, k = kt * 64 + 8 * g;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (r < rows && k + 8 <= L) v = *reinterpret_cast<const uint4*>(x + r * ld + k);
+  reinterpret_cast<uint4*>(t)[i] = v;
+}
+
 __device__ __attribute__((aligned(16))) float d_zero16[4] = {0, 0, 0, 0};
 static int64_t g_ld = 0;  // operand row stride (floats)
 static int g_dbg = 0;     // ablation bits for stamped builds
@@ -170,7 +184,7 @@ static void run(const char* name, const void* A, const float* inv, int64_t N, in
 }
 
 // the 8-phase 256 x 256 fp16 kernel (gemm_f16_8ph.hpp); general tile order or symmetric (upper triangle + mirror)
-template <bool SYMM, bool M16, bool STAMP = false>
+template <bool SYMM, bool M16, bool STAMP = false, bool TILED = false>
 static float run8(const char* name, const void* A, const float* inv, int64_t N, int64_t L, float* out, int ns,
                   const double* ref_h, const int* sm_h, const int* sn_h, int reps = 3) {
   GemmArgs g{};
@@ -182,7 +196,7 @@ static float run8(const char* name, const void* A, const float* inv, int64_t N, 
   CK(hipMemcpy(d_t, t.data(), t.size() * sizeof(GemmTile), hipMemcpyHostToDevice));
   g.tiles = d_t;
   const int total = (int)t.size();
-  auto kf = gemm_f16_8ph_kernel<SYMM, M16, STAMP>;
+  auto kf = gemm_f16_8ph_kernel<SYMM, M16, STAMP, TILED>;
   CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES));
   if (STAMP) CK(hipMalloc(&g.stamps, (size_t)total * 64));
   auto launch = [&]() { hipLaunchKernelGGL(kf, dim3((unsigned)total), dim3(512), G8_LDS_BYTES, 0, g); };
@@ -399,6 +413,10 @@ int main(int argc, char** argv) {
     std::vector<double> refh(ns);
     CK(hipMemcpy(refh.data(), d_ref, ns * 8, hipMemcpyDeviceToHost));
     const int rounds = argc > 5 ? atoi(argv[5]) : 3;
+    const int64_t nk_t = (L + 63) / 64, tiled_halfs = ((N + 127) / 128) * nk_t * 128 * 64;
+    _Float16* T16; CK(hipMalloc(&T16, (size_t)tiled_halfs * 2));
+    hipLaunchKernelGGL(to_tiled, dim3((unsigned)((tiled_halfs / 8 + 255) / 256)), dim3(256), 0, 0, A16, N, L, g_ld, T16, nk_t);
+    CK(hipDeviceSynchronize());
     for (int round = 0; round < rounds; ++round) {
       RUNH(256, 256, 2, 4, 2, false, 2, true, 1);
       run<256, 256, 2, 4, 2, false, 2, false, true, false, false, 8, true>("f16 256x256 ping-pong", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);
@@ -407,7 +425,9 @@ int main(int argc, char** argv) {
       RUNH(256, 256, 2, 4, 2, true, 2, false, 8);
       run8<true, true>("f16 8-phase 16x16x32 symm", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
       run8<true, false>("f16 8-phase 32x32x16 symm", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
+      run8<false, true, false, true>("f16 8-phase 16x16x32 TILED", T16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
     }
+    run8<false, true, true, true>("f16 8-phase 16x16x32 TILED stamped", T16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
     run8<false, true, true>("f16 8-phase 16x16x32 stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
     run8<false, false, true>("f16 8-phase 32x32x16 stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data());
     run<256, 256, 2, 4, 2, false, 2, true, true, false, true>("f16 256x256 shipped stamped", A16, inv, N, L, out, ns, refh.data(), sm.data(), sn.data(), 1);

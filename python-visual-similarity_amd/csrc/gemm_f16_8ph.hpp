@@ -44,7 +44,11 @@ __device__ __forceinline__ void g8_read(f32x4_t& dst, unsigned addr) {
 
 // SYMM: A == B, only tiles tn >= tm are listed, the mirrored tile is written through an LDS transpose.
 // STAMP: diagnostic build (variant harness): in-kernel clock of every workgroup.
-template <bool SYMM, bool M16, bool STAMP = false>
+// TILED (variant harness: an experiment on the operand layout): A and B point at a TILED copy of the rows --
+//   [row block of 128][k-tile][128 rows x 128 B, 16-B chunk g of row r stored at chunk g ^ ((r >> 1) & 7)], zero padded --
+// so that a half-tile is 16 KB of CONTIGUOUS memory in exactly the LDS image's order and an LDS-DMA instruction copies 1 KB
+// linearly (8 consecutive cache lines instead of one line from each of 8 rows 2 L bytes apart).
+template <bool SYMM, bool M16, bool STAMP = false, bool TILED = false>
 __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -85,8 +89,21 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmArgs g) {
   }
   const unsigned lds0 = lds_addr(smem);
   const int nk = (int)((g.L + 63) / 64);
-  const int nk_full = (int)(g.L / 64);                   // tiles [0, nk_full) are complete; tile nk_full (if < nk) is partial
+  const int nk_full = TILED ? nk : (int)(g.L / 64);      // tiles [0, nk_full) are complete; tile nk_full (if < nk) is partial
   const unsigned wave_lds = (unsigned)wave * 2048;
+  const char* tbase[4] = {nullptr, nullptr, nullptr, nullptr};   // TILED: the four half-tiles' row blocks at k-tile 0 (minus 1 KiB)
+  if constexpr (TILED) {
+    const int64_t nba = (g.M + 127) / 128, nbb = (g.N + 127) / 128;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      int64_t blk = (h < 2 ? m0 : n0) / 128 + (h & 1);
+      const int64_t nb = h < 2 ? nba : nbb;
+      blk = blk < nb ? blk : nb - 1;
+      tbase[h] = static_cast<const char*>(h < 2 ? g.A : g.B) + blk * (int64_t)nk * G8_HALF_BYTES - 1024;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) voff[h][q] = (unsigned)(wave * 2048 + lane * 16 + 1024);   // + q KiB comes from the immediate
+    }
+  }
 
   // stage half-tile H (0 A0, 1 A1, 2 B0, 3 B1) of k-tile t into buffer BUF
   auto stage = [&](auto H_, auto BUF_, int t) {
@@ -94,12 +111,19 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_8ph_kernel(GemmArgs g) {
     constexpr bool IS_A = H < 2;
     const unsigned dst = lds0 + (BUF * 4 + H) * G8_HALF_BYTES + wave_lds;
     if (t < nk_full) {
-      const char* sb = (IS_A ? base_a : base_b) + (int64_t)t * 128;
+      const char* sb = TILED ? tbase[H] + (int64_t)t * G8_HALF_BYTES : (IS_A ? base_a : base_b) + (int64_t)t * 128;
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
                    "global_load_lds_dwordx4 %2, %1\n\t"
                    "global_load_lds_dwordx4 %3, %1 offset:1024"
                    ::"s"(dst), "s"(sb), "v"(voff[H][0]), "v"(voff[H][1])
                    : "memory");
+    } else if constexpr (TILED) {
+      // a tile past the end: zeros (same instruction count)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g.zero16,
+                                         (__attribute__((address_space(3))) void*)(smem + (BUF * 4 + H) * G8_HALF_BYTES + wave * 2048 + q * 1024),
+                                         16, 0, 0);
     } else {
       // partial last tile or a tile past the end: chunks at or past L come from 16 B of zeros (same instruction count)
 #pragma unroll
