@@ -421,6 +421,7 @@ def rccl_unique_id(rank, world):
 
 
 def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # before anything initialises the HIP runtime (RCCL across processes)
     args = parse()
     if args.cpu_baseline_only:
         return cpu_baseline_child(args.images, args.total_queries or args.images, "fixed512" if args.workload == "corpus1m" else "ragged")
@@ -458,7 +459,6 @@ def main():
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     overlap = os.environ.get("PVS_BENCH_OVERLAP", "1") != "0"      # exchange overlapped with the (r, r) block (RCCL only)
 
     # N > 1: the engine works on the stream torch allocates / fills on, so a step needs no host synchronisation between encode,
