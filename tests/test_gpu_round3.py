@@ -168,3 +168,65 @@ def test_shipped_vocabularies_through_the_class_api():
     np.testing.assert_allclose(V, g["vlad_rootsift"], rtol=0, atol=5e-7)
     with pytest.raises(FileNotFoundError):
         GMMWeights.OXFORD102_K256_VGG16.load()        # absent from the reference's checkout too (.MISSING_LARGE_BLOBS:2)
+
+
+# ======================================================================================= the phase-scheduled fp16 GEMMs at ragged shapes
+@pytest.mark.parametrize("M,N,L", [(2100, 33000, 200), (1300, 52000, 136), (4100, 16500, 72)])
+def test_fp16_8phase_gemm_on_ragged_shapes(gpu_ctx, M, N, L):
+    """pvs_cosine_f16_dev on problems of more than four rounds of 256 x 256 tiles, so that the full rounds run on the 8-phase
+    kernel (gemm_f16_8ph.hpp) and the partly filled last round on the split-K two-stage kernel: rows / columns that do not fill
+    the edge tiles, L = 200 (three full k-tiles + a partial one: chunks past L staged from zeros, an even tile count), L = 136 (an
+    odd tile count: the second buffer of the last iteration is a zero tile), L = 72 (shorter than the prologue's look-ahead).
+    Reference: float64 dot products of the fp16-rounded operands."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(M + N + L)
+    a = torch.randn((M, L), generator=g, device=dev) * 0.3
+    b = torch.randn((N, L), generator=g, device=dev) * 0.3
+    b[5] = 0.0
+    a16, b16 = a.half().contiguous(), b.half().contiguous()
+    ia = (1.0 / a16.float().norm(dim=1)).contiguous()
+    ib = (1.0 / b16.float().norm(dim=1).clamp_min(1e-30)).contiguous()
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.cosine_f16_dev(a16.data_ptr(), M, b16.data_ptr(), N, L, ia.data_ptr(), ib.data_ptr(), out.data_ptr(), N)
+    gpu_ctx.sync()
+    ref = (a16.double() @ b16.double().T) * ia.double()[:, None] * ib.double()[None, :]
+    err = (out.double() - ref).abs().max().item()
+    assert torch.isfinite(out).all() and err < 2e-6, err
+    assert (out[:, 5] == 0).all()
+
+
+@pytest.mark.parametrize("nq,N,L,k", [(2100, 33000, 200, 10), (1100, 70000, 264, 5)])
+def test_filtered_topk_through_the_256x128_prefilter_kernel(gpu_ctx, nq, N, L, k):
+    """pvs_cosine_topk_filtered_dev on a query block x corpus large enough for the two-level 256 x 128 prefilter GEMM
+    (gemm_f16_2lvl.hpp: >= 4 rounds of tiles, general order), ragged in rows, columns and k-tiles (L = 200: partial last k-tile;
+    L = 264: five k-tiles, a count that is not a multiple of the three LDS buffers) and over more than one 32768-column panel:
+    indices AND float32 score bits identical to the exact path (f32 MFMA GEMM over all pairs + select)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(nq + N + L + k)
+    proto = torch.randn((300, L), generator=g, device=dev)
+    db = (proto[torch.randint(0, 300, (N,), generator=g, device=dev)] + 0.6 * torch.randn((N, L), generator=g, device=dev)).contiguous()
+    q = (db[torch.randint(0, N, (nq,), generator=g, device=dev)] + 0.3 * torch.randn((nq, L), generator=g, device=dev)).contiguous()
+    iq = torch.empty((nq,), dtype=torch.float32, device=dev)
+    idb = torch.empty((N,), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.row_inv_norms_dev(q.data_ptr(), nq, L, iq.data_ptr())
+    gpu_ctx.row_inv_norms_dev(db.data_ptr(), N, L, idb.data_ptr())
+    res = []
+    for filtered in (False, True):
+        idx = torch.full((nq, k), -7, dtype=torch.int64, device=dev)
+        val = torch.full((nq, k), -7.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        if filtered:
+            st = gpu_ctx.cosine_topk_filtered_dev(q.data_ptr(), nq, db.data_ptr(), N, L, iq.data_ptr(), idb.data_ptr(), k, idx.data_ptr(), val.data_ptr())
+            assert st["filtered"], "the prefilter declined: the test would compare the exact path with itself"
+        else:
+            gpu_ctx.cosine_topk_dev(q.data_ptr(), nq, db.data_ptr(), N, L, iq.data_ptr(), idb.data_ptr(), k, 0, False, idx.data_ptr(), val.data_ptr())
+        gpu_ctx.sync()
+        res.append((idx.cpu().numpy(), val.cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
