@@ -382,9 +382,9 @@ class GlooStagedComm:
 
     def all_gather(self, send, recv):
         import torch
-        o = torch.empty(recv.shape, dtype=recv.dtype)
-        self.dist.all_gather_into_tensor(o, send.contiguous().cpu())
-        recv.copy_(o)
+        o = torch.empty((recv.numel(),), dtype=recv.dtype)          # flat: recv may be (world, rows, L) or (world * rows, L)
+        self.dist.all_gather_into_tensor(o, send.contiguous().cpu().reshape(-1))
+        recv.view(-1).copy_(o)
 
     def all_to_all(self, out, inp):
         import torch
@@ -506,10 +506,18 @@ def main():
     enc16_loc = enc16_all = None
     if retr == "f16":
         enc16_loc = torch.empty((per, L), dtype=torch.float16, device=dev)
-        enc16_all = torch.empty((world * per, L), dtype=torch.float16, device=dev) if multi else enc16_loc
+        enc16_all = enc16_loc
+        if multi:
+            # the gathered fp16 corpus arrives in ROW CHUNKS of every rank's block (PVS_BENCH_XCHUNKS all-gathers instead of one),
+            # so that the scoring of chunk c overlaps the transfer of chunk c + 1: [chunk][rank][rows of the chunk][L]
+            xch = max(1, min(int(os.environ.get("PVS_BENCH_XCHUNKS", "4")), per))
+            per_c = -(-per // xch)
+            x_chunks = [(c * per_c, min(per, (c + 1) * per_c)) for c in range(xch) if c * per_c < per]
+            enc16_chunk = [torch.empty((world, c1 - c0, L), dtype=torch.float16, device=dev) for c0, c1 in x_chunks]
+            enc16_all = None
     nq = n_loc if args.queries <= 0 else min(n_loc, args.queries)            # query rows of this rank (all of them by default)
     if args.total_queries > 0:                                               # strong scaling: the queries are shared out
-        nq = max(1, min(n_loc, args.total_queries // world))
+        nq = min(n_loc, max(1, args.total_queries // world))
     idx = torch.empty((max(n_loc, 1), k_top), dtype=torch.int64, device=dev)
     val = torch.empty((max(n_loc, 1), k_top), dtype=torch.float32, device=dev)
 
@@ -588,10 +596,7 @@ def main():
         """Start the exchange of the encoded blocks on the exchange stream (after the encode on the compute stream); returns the
         call that makes the compute stream wait for it.  The gloo rehearsal stages through the host and is synchronous."""
         to_exchange_stream()
-        if retr == "f16":
-            comm.all_gather(enc16_loc, enc16_all)
-        else:
-            comm.all_gather(enc_loc, enc_all)
+        comm.all_gather(enc_loc, enc_all)
         comm.all_gather(inv_loc, inv_all)
         if staged or not overlap:
             from_exchange_stream()
@@ -601,21 +606,34 @@ def main():
     filt_stats = [None]
 
     def retrieve(filtered_now):
-        exchanged = exchange_begin() if multi else (lambda: None)
-        if retr == "f16" and multi and n_loc > 0:
-            # the rank's own block first, from its local copy, while the other blocks are still arriving; then the rows before
-            # and after it in the gathered corpus, merged into the same lists (rows [0, N) of the gathered array are the real
-            # ones: every block but the last is full)
-            e16 = enc16_all.element_size() * L
-            ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_loc.data_ptr(), n_loc, L, inv_loc.data_ptr(), inv_loc.data_ptr(), k_top,
-                                    lo, False, idx.data_ptr(), val.data_ptr())
-            exchanged()
-            if lo > 0:
-                ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_all.data_ptr(), lo, L, inv_loc.data_ptr(), inv_all.data_ptr(), k_top,
-                                        0, True, idx.data_ptr(), val.data_ptr())
-            if hi < N:
-                ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_all.data_ptr() + hi * e16, N - hi, L, inv_loc.data_ptr(),
-                                        inv_all.data_ptr() + hi * 4, k_top, hi, True, idx.data_ptr(), val.data_ptr())
+        exchanged = exchange_begin() if (multi and retr != "f16") else (lambda: None)
+        if retr == "f16" and multi:
+            # The rank's own block first, from its local copy, while the first chunk arrives; then, chunk by chunk, the rows of
+            # every other rank as soon as that chunk's all-gather has finished (the exchange stream runs ahead: the compute
+            # stream waits only for what had been queued there when it asked).  Every rank takes part in every collective,
+            # also one without rows or queries.
+            to_exchange_stream()                             # the exchange stream waits for the encode, nothing later
+            comm.all_gather(inv_loc, inv_all)
+            comm.all_gather(enc16_loc[x_chunks[0][0]:x_chunks[0][1]], enc16_chunk[0])
+            if not overlap or staged:
+                for ci in range(1, len(x_chunks)):
+                    comm.all_gather(enc16_loc[x_chunks[ci][0]:x_chunks[ci][1]], enc16_chunk[ci])
+            if nq > 0:
+                ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_loc.data_ptr(), n_loc, L, inv_loc.data_ptr(), inv_loc.data_ptr(), k_top,
+                                        lo, False, idx.data_ptr(), val.data_ptr())
+            from_exchange_stream()                           # chunk 0 (or, without overlap, everything) has arrived
+            for ci, (c0, c1) in enumerate(x_chunks):
+                if overlap and not staged and ci + 1 < len(x_chunks):
+                    comm.all_gather(enc16_loc[x_chunks[ci + 1][0]:x_chunks[ci + 1][1]], enc16_chunk[ci + 1])   # in flight under chunk ci's scoring
+                for r in range(world):
+                    g0 = r * per + c0
+                    nv = min(N, r * per + c1) - g0           # rows of rank r's block that exist in this chunk
+                    if r == rank or nv <= 0 or nq <= 0:
+                        continue
+                    ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_chunk[ci][r].data_ptr(), nv, L, inv_loc.data_ptr(),
+                                            inv_all.data_ptr() + g0 * 4, k_top, g0, True, idx.data_ptr(), val.data_ptr())
+                if overlap and not staged and ci + 1 < len(x_chunks):
+                    from_exchange_stream()
         elif retr == "f16":
             exchanged()
             ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_all.data_ptr(), N, L, inv_loc.data_ptr(), inv_all.data_ptr(), k_top,
