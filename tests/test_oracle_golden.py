@@ -314,3 +314,33 @@ def test_oracle_on_the_reference_shipped_tables():
     lab = np.concatenate([orc.kmeans_predict(x, C) for x in imgs])
     assert np.array_equal(lab, g["vlad_labels"])
     np.testing.assert_allclose(orc.vlad_encode(imgs, C), g["vlad_rootsift"], rtol=0, atol=2e-7)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/pyvisim/res/model_files"), reason="the reference checkout is only present in the build container")
+def test_shipped_table_files_equal_a_fresh_non_executing_read_of_the_reference():
+    """tests/golden/extract_reference_tables.py --check: the committed pvsim/res/model_files/*.npz are what the opcode walk
+    (no unpickling, no class lookups) reads out of the reference's own files today; a class record outside its allow-list
+    or an opcode outside its subset would stop it."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "golden", "extract_reference_tables.py"), "--check"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("same") == 13 and "DIFFERS" not in r.stdout          # 8 shipped files + 5 derived codebooks
+
+
+def test_the_table_reader_refuses_what_it_does_not_know(tmp_path):
+    """The reader is not an unpickler: a stream that names any other class, or uses an opcode outside the subset, is an error."""
+    import pickle
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    import extract_reference_tables as ext
+    p = tmp_path / "evil.pkl"
+    p.write_bytes(pickle.dumps(os.system, protocol=4))                         # a global the allow-list does not hold
+    with pytest.raises(ValueError, match="unexpected class record"):
+        ext.read_tables(str(p))
+    p.write_bytes(pickle.dumps({"a": 1.5, "b": [1, 2]}, protocol=0))           # protocol-0 opcodes are outside the subset
+    with pytest.raises(ValueError):
+        ext.read_tables(str(p))

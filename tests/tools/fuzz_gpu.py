@@ -93,6 +93,43 @@ def case_cosine_topk():
     assert np.array_equal(idx, order), ("topk", M, N, L, k)
 
 
+def case_cosine_f64():
+    """float64 operands: the f64 MFMA GEMM (even L, general / symmetric / split-K) or the vector-ALU kernel (odd L) + float64 ranking"""
+    M, N = int(rng.integers(1, 600)), int(rng.integers(1, 5000))
+    L = int(rng.choice([2, 3, 24, 130, 1000, 1023, 4098, 33000]))
+    if L >= 33000:
+        M, N = min(M, 200), min(N, 1500)
+    same = bool(rng.integers(0, 2))
+    a = rng.standard_normal((M, L)) * float(rng.choice([1e-6, 1.0, 1e5]))
+    b = a if same else rng.standard_normal((N, L))
+    if same:
+        N = M
+    if N > 3 and rng.integers(0, 2):
+        b[1] = b[0]
+        b[2] = 0.0
+    s = ctx.cosine(a, b)
+    ref = orc.cosine_similarity(a, b)
+    assert s.dtype == np.float64 and np.allclose(s, ref, rtol=0, atol=1e-13), ("cosine f64", M, N, L, same, float(np.abs(s - ref).max()))
+    if same:
+        assert np.array_equal(s, s.T), ("cosine f64 symmetry", M, L)
+    k = N if rng.integers(0, 4) == 0 else int(rng.integers(1, min(N, 60) + 1))
+    idx, val = ctx.cosine_topk_f64(a, b, k)
+    # (the host top-k form computes its own panels: general kernel for query blocks, symmetric when Q is DB -- same bits as `s`
+    # only where the same kernel and split produced them, so rank the scores it returns itself against `s` by value)
+    order = np.argsort(-s, axis=1, kind="stable")[:, :k]
+    want = np.take_along_axis(s, order, 1)
+    assert np.allclose(val, want, rtol=0, atol=1e-13), ("topk f64 values", M, N, L, k)
+    clear = np.ones_like(order, dtype=bool)
+    if k > 1:
+        gap = np.abs(np.diff(want, axis=1)) > 1e-12
+        clear[:, 1:] &= gap
+        clear[:, :-1] &= gap
+    if k < N:       # the first excluded score must be clearly below the last included one for that rank to be pinned
+        nxt = np.take_along_axis(s, np.argsort(-s, axis=1, kind="stable")[:, k:k + 1], 1)
+        clear[:, -1:] &= (want[:, -1:] - nxt) > 1e-12
+    assert np.array_equal(idx[clear], order[clear]), ("topk f64 order", M, N, L, k)
+
+
 def case_filtered():
     nq, N = int(rng.integers(1, 700)), int(rng.integers(2, 4000))
     L = int(rng.choice([8, 64, 1000, 1024, 2600, 4096, 8192]))
@@ -213,7 +250,7 @@ def case_learn():
     rows.free()
 
 
-cases = [case_vlad, case_fisher, case_cosine_topk, case_filtered, case_learn]
+cases = [case_vlad, case_fisher, case_cosine_topk, case_cosine_f64, case_filtered, case_learn]
 if os.environ.get("FUZZ_ONLY"):
     cases = [c for c in cases if c.__name__ == os.environ["FUZZ_ONLY"]]
 i = 0
