@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void cosine_gemm_generic_kernel(const T* __res
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int64_t m = m0 + ty * 4 + u, n = n0 + tx * 4 + v;
-      if (m < M && n < N) out[m * ldo + n] = acc[u][v] * (inva ? inva[m] : T(1)) * (invb ? invb[n] : T(1));
+      if (m < M && n < N) out[m * ldo + n] = acc[u][v] * ((inva ? inva[m] : T(1)) * (invb ? invb[n] : T(1)));   // sa*sb commutes: out[m][n] == out[n][m] bitwise for A == B
     }
 }
 

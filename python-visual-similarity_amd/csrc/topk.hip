@@ -591,6 +591,160 @@ __global__ __launch_bounds__(R64_THREADS) void rank_f64_kernel(const double* __r
   }
 }
 
+// Shallow float64 rankings (k <= 16) of complete rows: the one-wave-per-row threshold filter of topk_wave_kernel on 64-bit score
+// images -- a lane holds 16 scores of a 1024-column chunk, survivors of `score >= T` go to the wave's list as (image, column)
+// pairs, the list is ranked at the end by a bitonic sort across the lanes with the column as tie break.  Same total order as
+// rank_f64_kernel (score descending, index ascending, NaN last), so the same lists; that kernel sorts 8192 keys in LDS per
+// row whatever k is (8.6 ms for 8189 x 8189 scores, k = 5).
+constexpr int R64W_LIST = 256, R64W_ITEMS = 16, R64W_CHUNK = 64 * R64W_ITEMS;
+
+struct Key96 {
+  uint64_t m;
+  uint32_t i;
+};
+__device__ __forceinline__ bool key96_better(const Key96& a, const Key96& b) { return a.m > b.m || (a.m == b.m && a.i < b.i); }
+__device__ __forceinline__ Key96 wave_sort_desc96(Key96 v, int lane) {
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      Key96 o;
+      o.m = __shfl_xor(v.m, stride, 64);
+      o.i = __shfl_xor(v.i, stride, 64);
+      const bool keep_best = ((lane & stride) == 0) == ((lane & size) == 0);
+      const bool o_better = key96_better(o, v);
+      if (keep_best == o_better) v = o;
+    }
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64 * TKW_WAVES) void rank_f64_wave_kernel(const double* __restrict__ scores, int64_t nq, int64_t ncols, int64_t ld,
+                                                                       int k, int64_t* __restrict__ oidx, double* __restrict__ oval) {
+  __shared__ uint64_t cm_all[TKW_WAVES][R64W_LIST];
+  __shared__ uint32_t ci_all[TKW_WAVES][R64W_LIST];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * TKW_WAVES + wave;
+  if (q >= nq) return;
+  uint64_t* const cm = cm_all[wave];
+  uint32_t* const ci = ci_all[wave];
+  const double* const row = scores + q * ld;
+  int n = 0;
+  uint64_t T = 0ull;   // 0: no threshold yet (every real image is >= 1)
+  // list (n <= R64W_LIST) -> its best min(n, k) entries in cm / ci [0..), sorted; tightens T
+  auto list_topk = [&]() {
+    Key96 key[R64W_LIST / 64];
+#pragma unroll
+    for (int it = 0; it < R64W_LIST / 64; ++it) {
+      const int p = it * 64 + lane;
+      key[it].m = p < n ? cm[p] : 0ull;
+      key[it].i = p < n ? ci[p] : 0xffffffffu;
+    }
+    Key96 keep{0ull, 0xffffffffu};
+    for (int r = 0; r < k; ++r) {
+      Key96 mine{0ull, 0xffffffffu};
+#pragma unroll
+      for (int it = 0; it < R64W_LIST / 64; ++it)
+        if (key96_better(key[it], mine)) mine = key[it];
+      Key96 b = mine;
+      for (int sh = 32; sh >= 1; sh >>= 1) {
+        Key96 o;
+        o.m = __shfl_xor(b.m, sh, 64);
+        o.i = __shfl_xor(b.i, sh, 64);
+        if (key96_better(o, b)) b = o;
+      }
+      if (lane == r) keep = b;
+      if (b.m != 0ull && mine.m == b.m && mine.i == b.i) {
+#pragma unroll
+        for (int it = 0; it < R64W_LIST / 64; ++it)
+          if (key[it].m == b.m && key[it].i == b.i) key[it] = Key96{0ull, 0xffffffffu};
+      }
+    }
+    if (lane < k) { cm[lane] = keep.m; ci[lane] = keep.i; }
+    n = n < k ? n : k;
+    if (n == k) T = __shfl(keep.m, k - 1, 64);
+  };
+  for (int64_t c0 = 0; c0 < ncols; c0 += R64W_CHUNK) {
+    uint64_t m[R64W_ITEMS];
+#pragma unroll
+    for (int it = 0; it < R64W_ITEMS; ++it) {
+      const int64_t c = c0 + (int64_t)it * 64 + lane;
+      m[it] = c < ncols ? mono_f64(row[c]) : 0ull;
+    }
+    if (T == 0ull) {   // the k-th largest of the 64 lane maxima is reached by k columns of this chunk (0: fewer than k columns)
+      uint64_t mx = 0ull;
+#pragma unroll
+      for (int it = 0; it < R64W_ITEMS; ++it) mx = m[it] > mx ? m[it] : mx;
+      T = __shfl(wave_sort_desc(mx, lane), k - 1, 64);
+    }
+    const uint64_t thr = T == 0ull ? 1ull : T;
+    const int n0 = n;
+    bool overflow = false;
+#pragma unroll
+    for (int it = 0; it < R64W_ITEMS; ++it) {
+      const bool pass = m[it] >= thr;
+      const unsigned long long bm = __ballot(pass);
+      if (bm != 0ull) {
+        const int cnt = __popcll(bm);
+        if (n + cnt <= R64W_LIST) {
+          if (pass) {
+            const int p = n + __popcll(bm & ((1ull << lane) - 1ull));
+            cm[p] = m[it];
+            ci[p] = (uint32_t)(c0 + (int64_t)it * 64 + lane);
+          }
+        } else {
+          overflow = true;
+        }
+        n += cnt;
+      }
+    }
+    if (!overflow) {
+      if (n > R64W_LIST / 2) list_topk();
+      continue;
+    }
+    // heavily tied scores: best k of the list, then k rounds over the chunk's survivors and that list
+    n = n0;
+    list_topk();
+    Key96 lk{lane < n ? cm[lane] : 0ull, lane < n ? ci[lane] : 0xffffffffu};
+    Key96 keep{0ull, 0xffffffffu};
+    for (int r = 0; r < k; ++r) {
+      Key96 mine{0ull, 0xffffffffu};
+      int at = -1;
+#pragma unroll
+      for (int it = 0; it < R64W_ITEMS; ++it)
+        if (m[it] >= thr && m[it] > mine.m) { mine.m = m[it]; at = it; }   // strict '>': the lowest column among equal scores
+      if (at >= 0) mine.i = (uint32_t)(c0 + (int64_t)at * 64 + lane);
+      const bool from_list = key96_better(lk, mine);
+      if (from_list) mine = lk;
+      Key96 b = mine;
+      for (int sh = 32; sh >= 1; sh >>= 1) {
+        Key96 o;
+        o.m = __shfl_xor(b.m, sh, 64);
+        o.i = __shfl_xor(b.i, sh, 64);
+        if (key96_better(o, b)) b = o;
+      }
+      if (lane == r) keep = b;
+      if (b.m != 0ull && mine.m == b.m && mine.i == b.i) {
+        if (from_list) lk = Key96{0ull, 0xffffffffu};
+        else {
+#pragma unroll
+          for (int it = 0; it < R64W_ITEMS; ++it) m[it] = it == at ? 0ull : m[it];
+        }
+      }
+    }
+    if (lane < k) { cm[lane] = keep.m; ci[lane] = keep.i; }
+    n = __popcll(__ballot(lane < k && keep.m != 0ull));
+    if (n == k) T = __shfl(keep.m, k - 1, 64);
+  }
+  if (n > 64) list_topk();
+  const Key96 kk = wave_sort_desc96(Key96{lane < n ? cm[lane] : 0ull, lane < n ? ci[lane] : 0xffffffffu}, lane);
+  if (lane < k) {
+    const bool in = kk.m != 0ull;
+    oidx[q * k + lane] = in ? (int64_t)kk.i : -1;
+    oval[q * k + lane] = in ? unmono_f64(kk.m) : -INFINITY;
+  }
+}
+
 constexpr int R64_PAGE = R64_CHUNK / 2;
 
 int launch_rank_f64(pvs_ctx* ctx, const double* scores, int64_t nq, int64_t ncols, int64_t ld, int k, int64_t* d_idx, double* d_val) {
@@ -599,7 +753,10 @@ int launch_rank_f64(pvs_ctx* ctx, const double* scores, int64_t nq, int64_t ncol
   const size_t lds = (size_t)R64_CHUNK * 12;
   PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(rank_f64_kernel), lds));
   ScopedTimer tm(ctx, T_TOPK);
-  if (k <= R64_PAGE || ncols <= R64_CHUNK) {
+  if (k <= TKS_KMAX && ncols >= 2 * R64W_CHUNK && ctx->opt[PVS_OPT_TOPK_SELECT_ONLY] != 1) {
+    hipLaunchKernelGGL(rank_f64_wave_kernel, dim3((unsigned)((nq + TKW_WAVES - 1) / TKW_WAVES)), dim3(64 * TKW_WAVES), 0, ctx->stream, scores, nq,
+                       ncols, ld, k, d_idx, d_val);
+  } else if (k <= R64_PAGE || ncols <= R64_CHUNK) {
     hipLaunchKernelGGL(rank_f64_kernel, dim3((unsigned)nq), dim3(R64_THREADS), lds, ctx->stream, scores, ncols, ld, k, k, 0, d_idx, d_val);
   } else {
     // deeper than one page over more columns than the LDS buffer holds: page through the complete rows

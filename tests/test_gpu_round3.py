@@ -230,3 +230,29 @@ def test_filtered_topk_through_the_256x128_prefilter_kernel(gpu_ctx, nq, N, L, k
         res.append((idx.cpu().numpy(), val.cpu().numpy()))
     assert np.array_equal(res[0][0], res[1][0])
     assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+
+
+@pytest.mark.parametrize("nq,N,k", [(9, 2048, 5), (5, 30000, 10), (3, 9000, 16), (4, 2500, 1)])
+def test_float64_wave_ranking_equals_the_lds_sort(gpu_ctx, nq, N, k):
+    """k <= 16 over >= 2048 columns takes rank_f64_wave_kernel (one wave per row, threshold filter); PVS_OPT_TOPK_SELECT_ONLY = 1
+    pins the LDS bitonic kernel.  Same lists bit for bit on duplicated rows (tied scores), a zero row, NaN / +-inf scores and an
+    all-tied query (every score 0: the survivors overflow the list and the rounds fall-back ranks them)."""
+    from pvsim import _ffi
+    rng = np.random.default_rng(nq + N + k)
+    L = 6
+    db = rng.standard_normal((N, L))
+    db[1::5] = db[0::5][: len(db[1::5])]
+    db[7] = 0.0
+    q = rng.standard_normal((nq, L))
+    q[1] = 0.0                                        # all scores 0: everything ties
+    q[2, 0] = np.inf                                  # non-finite scores: NaN rank last
+    out = []
+    for opt in (1, 0):
+        gpu_ctx.set_option(_ffi.OPT_TOPK_SELECT_ONLY, opt)
+        out.append(gpu_ctx.cosine_topk_f64(q, db, k))
+    gpu_ctx.set_option(_ffi.OPT_TOPK_SELECT_ONLY, 0)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1].view(np.uint64), out[1][1].view(np.uint64))
+    full = gpu_ctx.cosine(q[3:], db)
+    order = np.argsort(-full, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(out[1][0][3:], order)

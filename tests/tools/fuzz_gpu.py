@@ -254,7 +254,11 @@ cases = [case_vlad, case_fisher, case_cosine_topk, case_cosine_f64, case_filtere
 if os.environ.get("FUZZ_ONLY"):
     cases = [c for c in cases if c.__name__ == os.environ["FUZZ_ONLY"]]
 i = 0
+t_say = time.time() + 30.0
 while time.time() < t_end:
+    if time.time() > t_say:          # a line every half minute: a silent long run looks hung to a job runner
+        print("fuzz progress", counts, flush=True)
+        t_say = time.time() + 30.0
     fn = cases[i % len(cases)]
     i += 1
     try:
