@@ -55,7 +55,7 @@ typedef enum {
   PVS_OPT_ASSIGN_PREFILTER = 0, /* 1 (default): fp16 MFMA prefilter + exact pass on near ties; 0: exact f32 MFMA kernel only      */
   PVS_OPT_VLAD_PATH = 1,        /* 0 (default) and 1: assign + gather aggregate (two reads of the descriptors); 2: assign +        */
                                 /* streaming aggregate; 3: fused one-read kernel (D = 128, 128 < K <= 256; error otherwise)        */
-  PVS_OPT_TOPK_SELECT_ONLY = 2, /* top-k kernel for k <= 16: 0 (default) threshold filter + rounds on panels of >= 16384 columns, rounds    */
+  PVS_OPT_TOPK_SELECT_ONLY = 2, /* top-k kernel for k <= 16: 0 (default) threshold filter on panels of >= 4096 columns, k rounds         */
                                 /* otherwise; 1: always the radix-select kernel; 2: always the rounds; 3: always the threshold filter  */
   PVS_OPT_AGG_VARIANT = 3,      /* gather aggregate at D <= 128: 0 (default) chosen by rows per cluster; 1: eight waves per SIMD,     */
                                 /* batches of 4 rows (short images); 2: five waves, batches of 8 (long images).  Same bits.         */

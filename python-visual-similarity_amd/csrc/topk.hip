@@ -459,7 +459,7 @@ static int launch_topk_impl(pvs_ctx* ctx, const TopkArgs& a) {
   ScopedTimer tm(ctx, T_TOPK);
   const int variant = ctx->opt[PVS_OPT_TOPK_SELECT_ONLY];   // 0 chosen here, 1 radix select, 2 rounds, 3 threshold filter + rounds
   const bool small = a.k <= TKS_KMAX && a.n_lists == 0 && a.out_off == 0 && a.out_ld == a.k && variant != 1;
-  if (small && (variant == 3 || (variant == 0 && a.ncols >= 2 * TK_CHUNK))) {
+  if (small && (variant == 3 || (variant == 0 && a.ncols >= 4096))) {
     const bool vec = a.ld % 4 == 0 && reinterpret_cast<uintptr_t>(a.scores) % 16 == 0;
     const unsigned grid = (unsigned)((a.nq + TKW_WAVES - 1) / TKW_WAVES);
     if (vec) hipLaunchKernelGGL(topk_wave_kernel<true>, dim3(grid), dim3(64 * TKW_WAVES), 0, ctx->stream, a);
