@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--queries", type=int, default=0, help="query rows per rank (0 = every local image: all-vs-all)")
     ap.add_argument("--total-queries", type=int, default=0,
                     help="query rows over ALL ranks (strong scaling: each rank ranks total/N of them); overrides --queries")
+    ap.add_argument("--prefilter-products", type=int, choices=[1, 2, 3], default=3,
+                    help="fp16 products per (row, cluster) of the assignment prefilter: 3 = the product path; 2 / 1 = measurement "
+                         "variants with a wider margin (more rows left to the exact kernel; same labels)")
     ap.add_argument("--fused", action="store_true", help="encode with the one-read fused kernel (PVS_OPT_VLAD_PATH = 3) instead of assign + aggregate")
     ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim", "learn", "corpus1m"], default=None,
                     help="default: config2 (BASELINE configs[1], the headline) with --gpus 1; corpus1m (configs[3]/[4]: 1M images "
@@ -257,6 +260,9 @@ def side_workload(args):
         if args.fused:
             from pvsim import _ffi
             ctx.set_option(_ffi.OPT_VLAD_PATH, _ffi.VLAD_PATH_FUSED)
+        if args.prefilter_products != 3:
+            from pvsim import _ffi
+            ctx.set_option(_ffi.OPT_ASSIGN_PREFILTER, {2: 2, 1: 3}[args.prefilter_products])
         from pvsim import synth
         proto = torch.from_numpy(synth.sift_prototypes().astype(np.float32)).to(dev)
         raw = torch.empty((N * n, DIM), dtype=torch.uint8, device=dev)
@@ -280,7 +286,8 @@ def side_workload(args):
                     "value": round(N / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "f32",
                     "scaling": "weak", "stages_ms_per_step": st,
                     "config": {"workload": f"{N} images x 512 SIFT-like descriptors ({args.desc}), VLAD K=256 encode only",
-                               "encode_path": "fused one-read kernel" if args.fused else "assign + aggregate"},
+                               "encode_path": "fused one-read kernel" if args.fused else "assign + aggregate",
+                               "prefilter_products": args.prefilter_products},
                     # the whole encode (assign + aggregate) against HBM: descriptors read twice (K1, K2) is what the kernels do,
                     # the algorithmic bytes count them once (393,216 B / image from f32 rows)
                     "roofline": {"kernel": "vlad_fused_kernel (one read)" if args.fused else "assign16_kernel + assign_kernel (near ties) + vlad_aggregate_kernel", "bound": "hbm",
@@ -485,6 +492,9 @@ def main():
     if args.fused:
         from pvsim import _ffi
         ctx.set_option(_ffi.OPT_VLAD_PATH, _ffi.VLAD_PATH_FUSED)
+    if args.prefilter_products != 3:
+        from pvsim import _ffi
+        ctx.set_option(_ffi.OPT_ASSIGN_PREFILTER, {2: 2, 1: 3}[args.prefilter_products])
 
     # ---- corpus, sharded by image: rank r owns images [lo, hi)
     N = args.images

@@ -212,12 +212,16 @@ struct Assign16Args {
   int64_t cap;
   float2* rowstat;               // uint8 rows: (row sum + 1e-7, its reciprocal) per descriptor for the aggregate pass, or null
   unsigned long long* stamps;    // diagnostic build (DIAG) only: [16] cycle totals over all workgroups, see pvs_fused_profile
+  int nprod;                     // fp16 products per (row, cluster): 3 (product path), 2 or 1 (measurement variants)
 };
 
 // STEPS: the number of 16-dim k-steps when it is known at compile time (8 for D_pad16 = 128), 0 = read it from the arguments.
 // With STEPS > 0 the whole cluster loop of a row block is straight-line code: table fragments are fetched from LDS one step
 // ahead of the MFMAs that use them, and the selection over one pair of tiles runs under the MFMAs of the next pair.
-template <int NT, int KIND, bool VEC, int STEPS, bool DIAG = false>
+// NP: fp16 products per (row, cluster): 3 = ch.xh + ch.xl + cl.xh (the product path), 2 = ch.xh + ch.xl (cl.xh dropped), 1 = ch.xh
+// only.  Fewer products widen the proven margin by 2^-11 |x||c| each, so more rows are left to the exact kernel -- the labels stay
+// the exact kernel's either way.  NP < 3 exists to MEASURE that trade (pvs_set_option(PVS_OPT_ASSIGN_PREFILTER, 2 | 3), STEPS > 0 only).
+template <int NT, int KIND, bool VEC, int STEPS, bool DIAG = false, int NP = 3>
 __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned int s_count;
@@ -500,15 +504,19 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
           // the three products of a tile go to the same accumulator in a fixed order; the tiles alternate so that an MFMA
           // never waits for the result of the one issued just before it.  (The group's first MFMA takes the constant 0 as its
           // accumulator input: no sixteen v_mov per tile to clear it.)
+          if constexpr (NP >= 3) {
+#pragma unroll
+            for (int tile = 0; tile < G2; ++tile)
+              acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[buf][tile], xh[t], t == 0 ? zero16 : acc[ab][tile], 0, 0, 0);
+          }
+          if constexpr (NP >= 2) {
+#pragma unroll
+            for (int tile = 0; tile < G2; ++tile)
+              acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[buf][tile], xl[t], (NP == 2 && t == 0) ? zero16 : acc[ab][tile], 0, 0, 0);
+          }
 #pragma unroll
           for (int tile = 0; tile < G2; ++tile)
-            acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[buf][tile], xh[t], t == 0 ? zero16 : acc[ab][tile], 0, 0, 0);
-#pragma unroll
-          for (int tile = 0; tile < G2; ++tile)
-            acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[buf][tile], xl[t], acc[ab][tile], 0, 0, 0);
-#pragma unroll
-          for (int tile = 0; tile < G2; ++tile)
-            acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[buf][tile], xh[t], acc[ab][tile], 0, 0, 0);
+            acc[ab][tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[buf][tile], xh[t], (NP == 1 && t == 0) ? zero16 : acc[ab][tile], 0, 0, 0);
           if (t == STEPS - 1) {                  // - |c|^2 / 2 . 2^(shifts), after every product of the group
 #pragma unroll
             for (int tile = 0; tile < G2; ++tile) {
@@ -592,7 +600,8 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
     // LUT rows: everything in units of 1 / sqrt(d) (|T| |c| instead of |x| |c|; |c|^2 sqrt(d) instead of |c|^2); the -|c|^2/2 term
     // additionally carries the dropped third piece of sqrt(d) (2^-22) and six accumulation roundings (6 2^-24): 6e-7 instead of 2.4e-7
     const float cc = LUT ? a.cmax * a.cmax * lut_sd : a.cmax * a.cmax;
-    const float eps = 2.f * (4.8e-7f + 2.4e-7f + 4.8e-5f + 7.7e-6f + 1e-9f + conv_err) * xc * (1.f + sqrt_d * 1e-9f) + (LUT ? 6.0e-7f : 2.4e-7f) * (cc + 2.f * xc);
+    constexpr float drop_err = (3 - NP) * 4.9e-4f;    // a dropped correction product: |cl| <= 2^-11 |c| or |xl| <= 2^-11 |x| element by element
+    const float eps = 2.f * (4.8e-7f + 2.4e-7f + 4.8e-5f + 7.7e-6f + 1e-9f + conv_err + drop_err) * xc * (1.f + sqrt_d * 1e-9f) + (LUT ? 6.0e-7f : 2.4e-7f) * (cc + 2.f * xc);
     const int within = second <= best + 2.f * eps ? 2 : 1;
     // settled: exactly one cluster within the margin (the minimum itself) and everything finite
     const bool settled = within == 1 && finite && fabsf(best) <= 3.0e38f && bidx < a.K;   // (a padded cluster never settles a row)
@@ -655,6 +664,10 @@ static int launch_assign16_nt(pvs_ctx* ctx, const Assign16Args& p, bool vec, siz
   auto ks = assign16_kernel<NT, KIND, false, 0>;
   auto k8 = assign16_kernel<NT, KIND, true, 8>;
   auto k = vec ? (p.D == 128 && p.D_pad16 == 128 ? k8 : kv) : ks;
+  if constexpr (NT == 8) {   // measurement variants of the shape the benchmarks use: two products / one product per (row, cluster)
+    if (k == k8 && p.nprod == 2) k = assign16_kernel<NT, KIND, true, 8, false, 2>;
+    if (k == k8 && p.nprod == 1) k = assign16_kernel<NT, KIND, true, 8, false, 1>;
+  }
   if constexpr (NT == 8) {   // pvs_fused_profile(ctx, 1, ...): the stamped build of the shape the benchmarks use
     if (p.stamps != nullptr && k == k8) k = assign16_kernel<NT, KIND, true, 8, true>;
   }
@@ -722,7 +735,7 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
     if (stat) *rowstat_out = rowstat;
     Assign16Args p{d_desc, total, cb->D, ld, static_cast<const _Float16*>(cb->d_c16), cb->d_cnorm, cb->K_pad, cb->D_pad16,
                    cb->c16_shift, cb->cmax, static_cast<const _Float16*>(cb->d_cnk), cb->cn_e1, cb->K, d_labels, rows, cnt, cap, rowstat,
-                   ctx->d_fused_stamps};
+                   ctx->d_fused_stamps, ctx->opt[PVS_OPT_ASSIGN_PREFILTER] == 2 ? 2 : (ctx->opt[PVS_OPT_ASSIGN_PREFILTER] == 3 ? 1 : 3)};
     const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4 + (size_t)cb->K_pad * 8 + 1024;   // + the sqrt table of uint8 rows
     PVS_TRY(launch_assign16(ctx, p, kind, cb->K_pad / 32, vec, lds16, grid));
     a.rows = rows;
