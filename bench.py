@@ -520,9 +520,7 @@ def main():
         if multi:
             # the gathered fp16 corpus arrives in ROW CHUNKS of every rank's block (PVS_BENCH_XCHUNKS all-gathers instead of one),
             # so that the scoring of chunk c overlaps the transfer of chunk c + 1: [chunk][rank][rows of the chunk][L]
-            xch = max(1, min(int(os.environ.get("PVS_BENCH_XCHUNKS", "4")), per))
-            per_c = -(-per // xch)
-            x_chunks = [(c * per_c, min(per, (c + 1) * per_c)) for c in range(xch) if c * per_c < per]
+            x_chunks, x_pieces = pd.exchange_chunks(N, world, int(os.environ.get("PVS_BENCH_XCHUNKS", "4")))
             enc16_chunk = [torch.empty((world, c1 - c0, L), dtype=torch.float16, device=dev) for c0, c1 in x_chunks]
             enc16_all = None
     nq = n_loc if args.queries <= 0 else min(n_loc, args.queries)            # query rows of this rank (all of them by default)
@@ -636,8 +634,7 @@ def main():
                 if overlap and not staged and ci + 1 < len(x_chunks):
                     comm.all_gather(enc16_loc[x_chunks[ci + 1][0]:x_chunks[ci + 1][1]], enc16_chunk[ci + 1])   # in flight under chunk ci's scoring
                 for r in range(world):
-                    g0 = r * per + c0
-                    nv = min(N, r * per + c1) - g0           # rows of rank r's block that exist in this chunk
+                    g0, nv = x_pieces[ci][r]                 # global index of rank r's first row in this chunk, rows that exist
                     if r == rank or nv <= 0 or nq <= 0:
                         continue
                     ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nq, enc16_chunk[ci][r].data_ptr(), nv, L, inv_loc.data_ptr(),

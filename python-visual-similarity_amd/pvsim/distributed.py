@@ -36,6 +36,19 @@ def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int, int]:
     return lo, min(n_total, lo + block), block
 
 
+def exchange_chunks(n_total: int, world: int, n_chunks: int):
+    """Row chunks of the block exchange (the fp16 retrieval scores chunk c while chunk c + 1 travels): every rank's block of
+    B = ceil(n_total / world) rows is cut at the same local offsets.  -> (chunks [(c0, c1) local row ranges], pieces) where
+    pieces[ci][r] = (global index of the first row, number of rows that exist) of rank r's part of chunk ci (0 rows past
+    n_total: only the last non-empty block is short).  All parts together tile [0, n_total) exactly once."""
+    _, _, block = shard_range(n_total, world, 0)
+    n_chunks = max(1, min(int(n_chunks), max(block, 1)))
+    per_c = -(-block // n_chunks)
+    chunks = [(c * per_c, min(block, (c + 1) * per_c)) for c in range(n_chunks) if c * per_c < block]
+    pieces = [[(r * block + c0, max(0, min(n_total, r * block + c1) - (r * block + c0))) for r in range(world)] for c0, c1 in chunks]
+    return chunks, pieces
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # device memory without torch
 class DevArray:

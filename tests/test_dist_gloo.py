@@ -215,3 +215,22 @@ def test_devarray_views_and_unique_id_bootstrap():
     finally:
         pd.new_unique_id = orig
     assert got == {0: uid, 1: uid, 2: uid}
+
+
+@pytest.mark.parametrize("n_total,world,n_chunks", [(1000000, 8, 4), (20000, 2, 4), (30011, 3, 3), (7, 4, 4), (5, 8, 2), (1030, 1, 4), (100, 3, 1)])
+def test_exchange_chunks_tile_the_corpus(n_total, world, n_chunks):
+    """bench.py's chunked fp16 exchange (chunk c scored while chunk c + 1 travels): the (rank, chunk) pieces cover every image
+    index exactly once, in the order of the blocks, and a rank's own pieces are exactly its block."""
+    from pvsim import distributed as pd
+    chunks, pieces = pd.exchange_chunks(n_total, world, n_chunks)
+    _, _, block = pd.shard_range(n_total, world, 0)
+    assert chunks[0][0] == 0 and chunks[-1][1] == block and all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
+    seen = np.zeros(n_total, np.int32)
+    for ci, (c0, c1) in enumerate(chunks):
+        for r in range(world):
+            g0, nv = pieces[ci][r]
+            assert g0 == r * block + c0 and 0 <= nv <= c1 - c0
+            seen[g0:g0 + nv] += 1
+            lo, hi, _ = pd.shard_range(n_total, world, r)
+            assert nv == 0 or (lo <= g0 and g0 + nv <= hi)
+    assert (seen == 1).all()
