@@ -75,7 +75,7 @@ struct pvs_ctx {
   // dynamic-LDS limits already raised on this context's device: kernel -> bytes
   std::map<const void*, int> lds_attr;
   // behaviour switches (pvs_set_option); defaults = the product path
-  int opt[PVS_OPT_COUNT_] = {1, 0, 0, 0};
+  int opt[PVS_OPT_COUNT_] = {1, 0, 0, 0, 0};
   unsigned int* d_queue = nullptr;   // image queue head of the fused encode (persistent workgroups)
   unsigned long long* d_fused_stamps = nullptr;   // non-null: fused launches run the stamped diagnostic kernel (pvs_fused_profile)
   // timers

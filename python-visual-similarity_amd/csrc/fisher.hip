@@ -421,6 +421,8 @@ struct MomMArgs {
   double* raw_s;        // RAW: [n_images][K][2D]  sum_i gamma x | sum_i gamma x**2
   double* raw_s0;       // RAW: [n_images][K]      sum_i gamma
   int resp_ld, k0;      // gamma row stride and first cluster of this launch (RAW over a mixture of more than 256 components)
+  int fold;             // != 0 (grid.x == 1): the workgroup walks ALL dim blocks of its image and divides by the norm itself
+  double eps;           // fold: added to the norm before dividing
 };
 
 __device__ __forceinline__ double power_norm64(double v, double p);
@@ -466,9 +468,21 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
   double* const lb0 = la0 + 2 * 256 * F64_KCP;              // [2][128 * F64_KCP]  Z chunk: [c][i], c = 64 wn + (x: 0..31 | x**2: 32..63)
   double* const s0s = lb0 + 2 * 128 * F64_KCP;              // [256]
   double* const red = s0s + 256;                            // [8]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int img = blockIdx.y;
+  // a.fold (non-RAW launches with grid.x == 1; measurement variant, see fisher_batch): this workgroup walks all dim blocks of its
+  // image, keeps the norm term of each (added in block order, exactly as fisher_scale_kernel adds the partials) and finally
+  // divides its own outputs, in place of the separate scale pass.
+  const bool fold = !RAW && a.fold != 0;
+  const int db_first = fold ? 0 : (int)blockIdx.x, db_last = fold ? a.dblocks : (int)blockIdx.x + 1;
+  double norm_total = 0.0;   // thread 0 only
+  for (int db = db_first; db < db_last; ++db) {
+  // the thread index is re-read behind an opaque barrier in every round: otherwise every per-thread index and address of the
+  // body is hoisted out of the dim-block loop and the kernel (128 accumulator registers) spills 76 registers
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
-  const int img = blockIdx.y, dblk = blockIdx.x * MM_DIMS, d0 = dblk + 32 * wn;
+  const int dblk = db * MM_DIMS, d0 = dblk + 32 * wn;
   const int64_t row0 = a.offsets[img];
   const int n = (int)(a.offsets[img + 1] - row0);
   const int K = a.K, D = a.D;
@@ -588,7 +602,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
         }
       }
     }
-  if (blockIdx.x == 0 && tid < K) {   // d_pi (fisher_vector.py:107,117)
+  if (db == 0 && tid < K) {   // d_pi (fisher_vector.py:107,117)
     const double w = a.w[tid];
     const double d_pi = n > 0 ? pnorm_t<PM>((s0s[tid] / dn - w) / sqrt(w), a.power) : 0.0;
     out[tid] = (OutT)d_pi;
@@ -605,7 +619,54 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
   if (tid == 0) {
     double t = red[0];
     for (int wv = 1; wv < 8; ++wv) t = is_max ? fmax(t, red[wv]) : t + red[wv];
-    a.partial[(int64_t)img * a.dblocks + blockIdx.x] = t;
+    if (fold) norm_total = is_max ? fmax(norm_total, t) : norm_total + t;
+    else a.partial[(int64_t)img * a.dblocks + db] = t;
+  }
+  __syncthreads();   // the staging buffers, s0s and red are reused by the next dim block
+  }   // dim blocks
+  if (fold) {
+    // the image's norm, as fisher_scale_kernel forms it; then every thread divides its share of the row the workgroup wrote
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+      const double nrm = a.norm_mode == 2 ? sqrt(norm_total) : (a.norm_mode == 0 ? pow(norm_total, 1.0 / a.norm_p) : norm_total);
+      red[0] = nrm + a.eps;
+    }
+    __syncthreads();   // also makes this workgroup's own global stores visible to all of its threads
+    const double den = red[0];
+    using OutT2 = std::conditional_t<OUT64, double, float>;
+    OutT2* const row = static_cast<OutT2*>(a.out) + (int64_t)img * ((int64_t)a.K + 2 * (int64_t)a.K * a.D);
+    const int64_t Lr = (int64_t)a.K + 2 * (int64_t)a.K * a.D;
+    // 16-byte accesses, four in flight per thread before the first division (one workgroup has to cover the latency of its own
+    // 1-2 MB row: element-at-a-time this tail cost more than the scale pass it replaces)
+    constexpr int V = 16 / (int)sizeof(OutT2);
+    using VecT = std::conditional_t<OUT64, double2, float4>;
+    int64_t done = 0;
+    if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+      const int64_t nvec = Lr / V;
+      VecT* const rv = reinterpret_cast<VecT*>(row);
+      int64_t i = tid;
+      for (; i + 3 * MM_THREADS < nvec; i += 4 * MM_THREADS) {
+        VecT v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = rv[i + u * MM_THREADS];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          OutT2* e = reinterpret_cast<OutT2*>(&v[u]);
+#pragma unroll
+          for (int c = 0; c < V; ++c) e[c] = (OutT2)((double)e[c] / den);
+          rv[i + u * MM_THREADS] = v[u];
+        }
+      }
+      for (; i < nvec; i += MM_THREADS) {
+        VecT v = rv[i];
+        OutT2* e = reinterpret_cast<OutT2*>(&v);
+#pragma unroll
+        for (int c = 0; c < V; ++c) e[c] = (OutT2)((double)e[c] / den);
+        rv[i] = v;
+      }
+      done = nvec * V;
+    }
+    for (int64_t i = done + tid; i < Lr; i += MM_THREADS) row[i] = (OutT2)((double)row[i] / den);
   }
 }
 
@@ -863,12 +924,21 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
   void* out_b = out_f64 ? static_cast<void*>(static_cast<double*>(d_out) + img0 * L)
                         : static_cast<void*>(static_cast<float*>(d_out) + img0 * L);
   ScopedTimer tm(ctx, T_FMOM);
+  bool folded = false;
   if (mfma) {
     MomMArgs m{x, D, ld, K, d_offsets + img0, resp_abs, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, prm.power_norm_weight, norm_mode, ord,
-               out_b, out_f64, partial, dblocks, nullptr, nullptr, K, 0};
+               out_b, out_f64, partial, dblocks, nullptr, nullptr, K, 0, 0, 0.0};
     const int pm = prm.power_norm_weight == 1.0 ? 0 : (prm.power_norm_weight == 0.5 ? 1 : 2);
     const int nm = norm_mode == 2 ? 2 : (norm_mode == 0 ? 0 : 1);
-    const dim3 grid((unsigned)dblocks, (unsigned)n_img);
+    // measurement variant (PVS_OPT_FISHER_SCALE = 1): one workgroup per image walks the dim blocks and divides the row itself.
+    // At configs[2] on one box: 25.3 ms against 24.2 ms for moments + scale pass (f32 rows), 29.9 against 27.0 (f64 rows) -- the
+    // moments kernel runs at 54 % of the f64 MFMA rate with its epilogue on the vector ALUs, so there is no idle time for the tail
+    // to hide in, and one workgroup's tail has 32 KB in flight where the scale pass has the whole chip's.
+    const bool fold = ctx->opt[PVS_OPT_FISHER_SCALE] == 1;
+    m.fold = fold ? 1 : 0;
+    m.eps = prm.epsilon;
+    const dim3 grid(fold ? 1u : (unsigned)dblocks, (unsigned)n_img);
+    folded = fold;
 #define PVS_MOM(PMV, NMV)                                                                             \
   do {                                                                                                \
     if (out_f64) PVS_TRY((launch_moments<false, PMV, NMV, true>(ctx, grid, m)));                      \
@@ -893,6 +963,7 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
     else hipLaunchKernelGGL((fisher_moments_kernel<256, false>), grid, dim3(256), 0, ctx->stream, a);
   }
   PVS_HIP(hipGetLastError());
+  if (folded) return PVS_OK;
   const unsigned sx = (unsigned)std::min<int64_t>((L + 255) / 256, 64);
   hipLaunchKernelGGL(fisher_scale_kernel, dim3(sx, (unsigned)n_img), dim3(256), 0, ctx->stream, out_b, out_f64, L, partial, bpi,
                      norm_mode, ord, prm.epsilon);

@@ -20,7 +20,7 @@ _EXC = {PVS_ERR_INVALID: ValueError, PVS_ERR_NO_DEVICE: RuntimeError, PVS_ERR_OO
         PVS_ERR_UNSUPPORTED: NotImplementedError, PVS_ERR_DIM: RuntimeError}
 
 DESC_F32, DESC_F32_ROOTSIFT, DESC_U8_ROOTSIFT = 0, 1, 2
-OPT_ASSIGN_PREFILTER, OPT_VLAD_PATH, OPT_TOPK_SELECT_ONLY, OPT_AGG_VARIANT = 0, 1, 2, 3      # pvs_option
+OPT_ASSIGN_PREFILTER, OPT_VLAD_PATH, OPT_TOPK_SELECT_ONLY, OPT_AGG_VARIANT, OPT_FISHER_SCALE = 0, 1, 2, 3, 4      # pvs_option
 VLAD_PATH_AUTO, VLAD_PATH_GATHER, VLAD_PATH_STREAM, VLAD_PATH_FUSED = 0, 1, 2, 3
 TIMER_NAMES = ("assign", "aggregate", "cosine_gemm", "topk", "fisher_posterior", "fisher_moments", "misc", "rescore")
 

@@ -256,3 +256,42 @@ def test_float64_wave_ranking_equals_the_lds_sort(gpu_ctx, nq, N, k):
     full = gpu_ctx.cosine(q[3:], db)
     order = np.argsort(-full, axis=1, kind="stable")[:, :k]
     assert np.array_equal(out[1][0][3:], order)
+
+
+# ======================================================================================= Fisher: norm division inside the moments kernel
+@pytest.mark.parametrize("kw", [dict(), dict(power=1.0, norm_order=1), dict(power=0.3, norm_order=3), dict(power=0.5, norm_order=np.inf)],
+                         ids=["sqrt-l2", "p1-l1", "p0.3-l3", "sqrt-inf"])
+def test_fisher_rows_divided_inside_the_moments_kernel_equal_the_two_pass_form(gpu_ctx, kw):
+    """PVS_OPT_FISHER_SCALE = 1 (measurement variant): one workgroup walks all dim blocks of its image and divides the row by its
+    norm itself instead of the separate scale pass.  Ragged images (empty ones included; D = 96 leaves a partial dim block; K = 41
+    leaves rows that are not 16-byte aligned) through both forms and in calls of 200: the rows must agree bit for bit, and agree
+    with the NumPy restatement (fisher_vector.py:94-127) within the Fisher tolerance."""
+    from pvsim import pack_descriptors, _ffi
+    FISHER_ATOL = 1e-9
+    rng = np.random.default_rng(77)
+    for K, D, N in ((40, 96, 600), (41, 64, 520)):
+        w = rng.random(K) + 0.2
+        w /= w.sum()
+        mu = rng.normal(size=(K, D))
+        cov = rng.random((K, D)) + 0.3
+        counts = rng.integers(0, 70, size=N)
+        counts[[3, N - 1]] = 0
+        imgs = [rng.normal(size=(int(c), D)).astype(np.float32) for c in counts]
+        gm = gpu_ctx.gmm(w, mu, cov)
+        packed, off = pack_descriptors(imgs, D, np.float32)
+        one = gpu_ctx.fisher_encode(gm, packed, off, **kw)
+        two_pass = one
+        with gpu_ctx.option(_ffi.OPT_FISHER_SCALE, 1):
+            in_kernel = gpu_ctx.fisher_encode(gm, packed, off, **kw)
+            few = gpu_ctx.fisher_encode(gm, packed[: off[5]], off[:6], **kw)
+        parts = []
+        for s in range(0, N, 200):
+            e = min(N, s + 200)
+            parts.append(gpu_ctx.fisher_encode(gm, packed[off[s]:off[e]], off[s:e + 1] - off[s], **kw))
+        assert np.array_equal(one, two_pass) and np.array_equal(one, in_kernel) and np.array_equal(one, np.concatenate(parts))
+        assert np.array_equal(few, one[:5])
+        assert not one[3].any() and not one[N - 1].any()
+        okw = dict(power=kw.get("power", 0.5), norm_order=kw.get("norm_order", 2))
+        sel = [0, 1, 2, 3, 4, 300, N - 2]
+        ref = orc.fisher_encode([imgs[i] for i in sel], w, mu, cov, **okw)
+        np.testing.assert_allclose(one[sel], ref, rtol=0, atol=FISHER_ATOL)
