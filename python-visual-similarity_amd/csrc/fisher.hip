@@ -239,17 +239,18 @@ static int posterior_on(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 constexpr int F64_KC = 16, F64_KCP = F64_KC + 1;
 
-template <int MI, int NI>
+template <int MI, int NI, int KC = F64_KC>
 __device__ __forceinline__ void f64_chunk_mma(const double* la, const double* lb, int arow0, int bcol0, int lane,
                                               f64x4_t (&acc)[MI][NI]) {
+  constexpr int KCP = KC + 1;
   const int r = lane & 15, kk = lane >> 4;
 #pragma unroll
-  for (int ks = 0; ks < F64_KC / 4; ++ks) {
+  for (int ks = 0; ks < KC / 4; ++ks) {
     double a[MI], b[NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a[mi] = la[(arow0 + 16 * mi + r) * F64_KCP + 4 * ks + kk];
+    for (int mi = 0; mi < MI; ++mi) a[mi] = la[(arow0 + 16 * mi + r) * KCP + 4 * ks + kk];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b[ni] = lb[(bcol0 + 16 * ni + r) * F64_KCP + 4 * ks + kk];
+    for (int ni = 0; ni < NI; ++ni) b[ni] = lb[(bcol0 + 16 * ni + r) * KCP + 4 * ks + kk];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -397,10 +398,16 @@ __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostM
 // ------------------------------------------------------------------------------------ K5 on fp64 MFMA (fused)
 // Per image:  S[k][c] = sum_i gamma[i][k] * Z[i][c]  (inner dimension n_i), then the gradients, the power norm and
 // this block's share of the global norm -- the raw sums never leave the registers.
-// Block = (image, 64 dims), 8 waves: wave (wm = wave & 3, wn = wave >> 2) owns cluster rows [64 wm, +64) and the 64
-// columns Z = [x_d (32) | x_d**2 (32)] of dims d0 + 32 wn + [0, 32), so that the lane holding S1[k][d] (column tile
-// ni) also holds S2[k][d] (tile ni + 2).  s0[k] = sum_i gamma[i][k] is summed by thread k from the staged gamma^T
-// chunks (descriptor order).  The gamma^T chunk (32 KiB) is staged once per 128 columns.
+// Block = (image, 32 dims), 4 waves: wave wm owns cluster rows [64 wm, +64) and the 64 columns Z = [x_d (32) | x_d**2 (32)]
+// of dims d0 + [0, 32), so that the lane holding S1[k][d] (column tile ni) also holds S2[k][d] (tile ni + 2).
+// s0[k] = sum_i gamma[i][k] is summed by thread k from the staged gamma^T chunks (descriptor order).
+// Shape: the accumulators take 128 of a wave's 256 registers, so a CU holds 8 waves.  As ONE workgroup of 8 waves (round 1-2:
+// 64 dims, chunks of 16 descriptors, 104 KB of LDS) all of them sit in the same phase -- the MFMA loop (10.7 ms of pipe time at
+// configs[2]) and the epilogue (two fp64 square roots per output on the vector ALUs) ran one after the other: 19.7 ms, pipe 56 %
+// busy.  As TWO workgroups of 4 waves (chunks of 8 descriptors, 46 KB each) the phases of the two drift apart and one's
+// epilogue runs under the other's MFMA loop.  The dim blocks of an image are mapped to ONE XCD, next to each other in its
+// dispatch order, so that the image's gamma rows (400 KB at configs[2], read by every dim block) come from HBM once instead
+// of once per XCD (28.6 GB fetched for 6.6 GB of operands before).
 struct MomMArgs {
   const float* X;
   int D, ld, K;
@@ -421,8 +428,9 @@ struct MomMArgs {
   double* raw_s;        // RAW: [n_images][K][2D]  sum_i gamma x | sum_i gamma x**2
   double* raw_s0;       // RAW: [n_images][K]      sum_i gamma
   int resp_ld, k0;      // gamma row stride and first cluster of this launch (RAW over a mixture of more than 256 components)
-  int fold;             // != 0 (grid.x == 1): the workgroup walks ALL dim blocks of its image and divides by the norm itself
+  int fold;             // != 0 (one workgroup per image): the workgroup walks ALL dim blocks of its image and divides by the norm itself
   double eps;           // fold: added to the norm before dividing
+  int64_t n_img;        // images (RAW: descriptor chunks) of this launch
 };
 
 __device__ __forceinline__ double power_norm64(double v, double p);
@@ -433,7 +441,7 @@ __device__ __forceinline__ void store_out(void* out, int f64, int64_t i, T v) {
   else static_cast<float*>(out)[i] = (float)v;
 }
 
-constexpr int MM_THREADS = 512, MM_DIMS = 64;
+constexpr int MM_THREADS = 256, MM_DIMS = 32, MM_KC = 8, MM_KCP = MM_KC + 1;
 
 // The fused epilogue is instantiated per (power, norm) case: with p and the norm order as run-time values every one of
 // its 64 unrolled outputs carried an inlined pow() (18k instructions, 110 KB of code -- twice the instruction cache --
@@ -464,25 +472,37 @@ template <bool RAW, int PM = 2, int NM = 0, bool OUT64 = true>
 __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomMArgs a) {
   // double-buffered chunks (global loads of chunk c+1 in flight during the MFMAs of chunk c)
   extern __shared__ __attribute__((aligned(16))) char mm_smem[];
-  double* const la0 = reinterpret_cast<double*>(mm_smem);   // [2][256 * F64_KCP]  gamma^T chunk: [k][i]
-  double* const lb0 = la0 + 2 * 256 * F64_KCP;              // [2][128 * F64_KCP]  Z chunk: [c][i], c = 64 wn + (x: 0..31 | x**2: 32..63)
-  double* const s0s = lb0 + 2 * 128 * F64_KCP;              // [256]
+  double* const la0 = reinterpret_cast<double*>(mm_smem);   // [2][256 * MM_KCP]  gamma^T chunk: [k][i]
+  double* const lb0 = la0 + 2 * 256 * MM_KCP;               // [2][64 * MM_KCP]   Z chunk: [c][i], c = (x: 0..31 | x**2: 32..63)
+  double* const s0s = lb0 + 2 * 64 * MM_KCP;                // [256]
   double* const red = s0s + 256;                            // [8]
-  const int img = blockIdx.y;
-  // a.fold (non-RAW launches with grid.x == 1; measurement variant, see fisher_batch): this workgroup walks all dim blocks of its
+  // a.fold (non-RAW, one workgroup per image; measurement variant, see fisher_batch): this workgroup walks all dim blocks of its
   // image, keeps the norm term of each (added in block order, exactly as fisher_scale_kernel adds the partials) and finally
   // divides its own outputs, in place of the separate scale pass.
   const bool fold = !RAW && a.fold != 0;
-  const int db_first = fold ? 0 : (int)blockIdx.x, db_last = fold ? a.dblocks : (int)blockIdx.x + 1;
+  // Otherwise workgroup b runs on XCD b % 8 (round-robin dispatch), as that XCD's (b / 8)-th: images are dealt to the XCDs in
+  // groups of 8 and an XCD walks the dim blocks of its image before it moves to the next group.
+  int img, db_first, db_last;
+  if (fold) {
+    img = blockIdx.x;
+    db_first = 0;
+    db_last = a.dblocks;
+  } else {
+    const int64_t seq = (int64_t)(blockIdx.x >> 3);
+    const int64_t im = (seq / a.dblocks) * 8 + (blockIdx.x & 7);
+    if (im >= a.n_img) return;
+    img = (int)im;
+    db_first = (int)(seq % a.dblocks);
+    db_last = db_first + 1;
+  }
   double norm_total = 0.0;   // thread 0 only
   for (int db = db_first; db < db_last; ++db) {
   // the thread index is re-read behind an opaque barrier in every round: otherwise every per-thread index and address of the
   // body is hoisted out of the dim-block loop and the kernel (128 accumulator registers) spills 76 registers
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 3, wn = wave >> 2;
-  const int dblk = db * MM_DIMS, d0 = dblk + 32 * wn;
+  const int lane = tid & 63, wm = tid >> 6;
+  const int dblk = db * MM_DIMS, d0 = dblk;
   const int64_t row0 = a.offsets[img];
   const int n = (int)(a.offsets[img + 1] - row0);
   const int K = a.K, D = a.D;
@@ -494,35 +514,24 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f64x4_t{0.0, 0.0, 0.0, 0.0};
   double s0 = 0.0;
 
-  // staging: gamma: thread t takes cluster k = t & 255 of descriptors (t >> 8) + 2 q, q < 8 (consecutive threads ->
-  // consecutive clusters); Z: dim dd = t & 63 of descriptors (t >> 6) + 8 q, q < 2
-  const int gk = tid & 255, gi = tid >> 8, zd = tid & 63, zi = tid >> 6;
-  const int zc = 64 * (zd >> 5) + (zd & 31);
-  double gv[8];
-  float zv[2];
+  // staging: gamma: thread t takes cluster k = t of the chunk's 8 descriptors (consecutive threads -> consecutive clusters);
+  // Z: dim dd = t & 31 of descriptor t >> 5
+  const int gk = tid, zd = tid & 31, zi = tid >> 5;
+  double gv[MM_KC];
+  float zv;
   auto fetch = [&](int i0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int ii = gi + 2 * q;
-      gv[q] = (i0 + ii < n && gk < K) ? a.resp[(row0 + i0 + ii) * a.resp_ld + a.k0 + gk] : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int ii = zi + 8 * q;
-      zv[q] = (i0 + ii < n && dblk + zd < D) ? a.X[(row0 + i0 + ii) * a.ld + dblk + zd] : 0.f;
-    }
+    for (int q = 0; q < MM_KC; ++q)
+      gv[q] = (i0 + q < n && gk < K) ? a.resp[(row0 + i0 + q) * a.resp_ld + a.k0 + gk] : 0.0;
+    zv = (i0 + zi < n && dblk + zd < D) ? a.X[(row0 + i0 + zi) * a.ld + dblk + zd] : 0.f;
   };
   auto stash = [&](int buf) {
-    double* la = la0 + buf * (256 * F64_KCP);
-    double* lb = lb0 + buf * (128 * F64_KCP);
+    double* la = la0 + buf * (256 * MM_KCP);
+    double* lb = lb0 + buf * (64 * MM_KCP);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) la[gk * F64_KCP + gi + 2 * q] = gv[q];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int ii = zi + 8 * q;
-      lb[zc * F64_KCP + ii] = (double)zv[q];
-      lb[(zc + 32) * F64_KCP + ii] = (double)(zv[q] * zv[q]);   // np.power(descriptors, 2) in fp32 (fisher_vector.py:104)
-    }
+    for (int q = 0; q < MM_KC; ++q) la[gk * MM_KCP + q] = gv[q];
+    lb[zd * MM_KCP + zi] = (double)zv;
+    lb[(zd + 32) * MM_KCP + zi] = (double)(zv * zv);   // np.power(descriptors, 2) in fp32 (fisher_vector.py:104)
   };
   if (n > 0) {
     fetch(0);
@@ -530,20 +539,18 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
   }
   __syncthreads();
   int buf = 0;
-  for (int i0 = 0; i0 < n; i0 += F64_KC) {
-    const bool more = i0 + F64_KC < n;
-    if (more) fetch(i0 + F64_KC);
-    const double* la = la0 + buf * (256 * F64_KCP);
-    if (tid < 256) {
+  for (int i0 = 0; i0 < n; i0 += MM_KC) {
+    const bool more = i0 + MM_KC < n;
+    if (more) fetch(i0 + MM_KC);
+    const double* la = la0 + buf * (256 * MM_KCP);
 #pragma unroll
-      for (int ii = 0; ii < F64_KC; ++ii) s0 += la[tid * F64_KCP + ii];   // zeros past n; descriptor order
-    }
-    f64_chunk_mma<4, 4>(la, lb0 + buf * (128 * F64_KCP), wm * 64, wn * 64, lane, acc);
+    for (int ii = 0; ii < MM_KC; ++ii) s0 += la[tid * MM_KCP + ii];   // zeros past n; descriptor order
+    f64_chunk_mma<4, 4, MM_KC>(la, lb0 + buf * (64 * MM_KCP), wm * 64, 0, lane, acc);
     if (more) stash(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
-  if (tid < 256) s0s[tid] = s0;
+  s0s[tid] = s0;
   __syncthreads();
 
   if constexpr (RAW) {
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
           o[D + d] = acc[mi][ni + 2][r];
         }
       }
-    if (blockIdx.x == 0 && tid < K) a.raw_s0[(int64_t)img * K + tid] = s0s[tid];
+    if (db == 0 && tid < K) a.raw_s0[(int64_t)img * K + tid] = s0s[tid];
     return;
   }
 
@@ -614,11 +621,11 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
     const double o = __shfl_xor(part, m, 64);
     part = is_max ? fmax(part, o) : part + o;
   }
-  if (lane == 0) red[wave] = part;
+  if (lane == 0) red[wm] = part;
   __syncthreads();
   if (tid == 0) {
     double t = red[0];
-    for (int wv = 1; wv < 8; ++wv) t = is_max ? fmax(t, red[wv]) : t + red[wv];
+    for (int wv = 1; wv < MM_THREADS / 64; ++wv) t = is_max ? fmax(t, red[wv]) : t + red[wv];
     if (fold) norm_total = is_max ? fmax(norm_total, t) : norm_total + t;
     else a.partial[(int64_t)img * a.dblocks + db] = t;
   }
@@ -670,12 +677,15 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
   }
 }
 
-constexpr size_t MM_LDS = (size_t)(2 * 256 * F64_KCP + 2 * 128 * F64_KCP + 256 + 8) * sizeof(double);
+constexpr size_t MM_LDS = (size_t)(2 * 256 * MM_KCP + 2 * 64 * MM_KCP + 256 + 8) * sizeof(double);
 template <bool RAW, int PM, int NM, bool OUT64>
-static int launch_moments(pvs_ctx* ctx, dim3 grid, const MomMArgs& m) {
+static int launch_moments(pvs_ctx* ctx, const MomMArgs& m) {
   auto k = fisher_moments_mfma_kernel<RAW, PM, NM, OUT64>;
   PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(k), MM_LDS));
-  hipLaunchKernelGGL(k, grid, dim3(MM_THREADS), MM_LDS, ctx->stream, m);
+  // one workgroup per (image, dim block), images padded to groups of 8 (one per XCD); fold: one workgroup per image
+  const int64_t nblk = m.fold ? m.n_img : (m.n_img + 7) / 8 * 8 * m.dblocks;
+  if (nblk > 0x7fffffffLL) PVS_FAIL(PVS_ERR_INVALID, "Fisher moments: %lld workgroups in one launch", (long long)nblk);
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(MM_THREADS), MM_LDS, ctx->stream, m);
   return PVS_OK;
 }
 
@@ -927,7 +937,7 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
   bool folded = false;
   if (mfma) {
     MomMArgs m{x, D, ld, K, d_offsets + img0, resp_abs, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, prm.power_norm_weight, norm_mode, ord,
-               out_b, out_f64, partial, dblocks, nullptr, nullptr, K, 0, 0, 0.0};
+               out_b, out_f64, partial, dblocks, nullptr, nullptr, K, 0, 0, 0.0, n_img};
     const int pm = prm.power_norm_weight == 1.0 ? 0 : (prm.power_norm_weight == 0.5 ? 1 : 2);
     const int nm = norm_mode == 2 ? 2 : (norm_mode == 0 ? 0 : 1);
     // measurement variant (PVS_OPT_FISHER_SCALE = 1): one workgroup per image walks the dim blocks and divides the row itself.
@@ -937,12 +947,11 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
     const bool fold = ctx->opt[PVS_OPT_FISHER_SCALE] == 1;
     m.fold = fold ? 1 : 0;
     m.eps = prm.epsilon;
-    const dim3 grid(fold ? 1u : (unsigned)dblocks, (unsigned)n_img);
     folded = fold;
 #define PVS_MOM(PMV, NMV)                                                                             \
   do {                                                                                                \
-    if (out_f64) PVS_TRY((launch_moments<false, PMV, NMV, true>(ctx, grid, m)));                      \
-    else PVS_TRY((launch_moments<false, PMV, NMV, false>(ctx, grid, m)));                             \
+    if (out_f64) PVS_TRY((launch_moments<false, PMV, NMV, true>(ctx, m)));                            \
+    else PVS_TRY((launch_moments<false, PMV, NMV, false>(ctx, m)));                                   \
   } while (0)
     if (pm == 1 && nm == 2) PVS_MOM(1, 2);        // the reference's defaults: p = 0.5, L2
     else if (pm == 0 && nm == 2) PVS_MOM(0, 2);
@@ -1012,8 +1021,8 @@ int launch_gmm_em_step(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, i
       {
         ScopedTimer tm(ctx, T_FMOM);
         MomMArgs m{x, D, ld, ks, off, resp - t0 * K, g->d_w, g->d_mu, g->d_cov, g->d_inv_mu, g->d_inv_sg, 1.0, 2, 2.0,
-                   nullptr, 1, nullptr, dblocks, raw, raw0, K, k0};
-        PVS_TRY((launch_moments<true, 2, 0, true>(ctx, dim3((unsigned)dblocks, (unsigned)nch), m)));
+                   nullptr, 1, nullptr, dblocks, raw, raw0, K, k0, 0, 0.0, nch};
+        PVS_TRY((launch_moments<true, 2, 0, true>(ctx, m)));
       }
       const int64_t sl_len = (int64_t)ks * 2 * D;
       hipLaunchKernelGGL(reduce_chunks_kernel<double>, dim3((unsigned)((ks + 255) / 256)), dim3(256), 0, ctx->stream, raw0, nch, (int64_t)ks,

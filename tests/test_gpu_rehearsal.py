@@ -77,6 +77,25 @@ def test_corpus1m_single_gpu_filtered_equals_exact():
     assert line["self_check"]["lists_bit_identical_to_plain_exact_ranking"] is True and line["n_gpus"] == 1
 
 
+@pytest.mark.parametrize("retrieval,qflag,nq", [("f16", "--total-queries", 4096), ("filtered", "--queries", 2048)])
+def test_corpus1m_at_its_stated_size_on_one_gpu(retrieval, qflag, nq):
+    """BASELINE configs[3] / configs[4] at their stated size, on the one GPU a test has: 1,000,000 images x 512 uint8 descriptors
+    generated and encoded chunk by chunk (202 GB resident), then a query block ranked against all 10^6 rows.  f16 = configs[4]'s
+    fp16 MFMA similarity (recall@10 of 256 sampled queries against their exact fp32 lists); filtered = the exact lists through
+    the fp16 prefilter + fp32 re-scoring, bit-identical on 256 sampled queries to the all-pairs fp32 GEMM.  Size-independent
+    properties at full size: every query retrieves itself first with score 1 (asserted inside bench.py for both paths)."""
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--workload", "corpus1m", "--retrieval", retrieval,
+                        qflag, str(nq), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["images"] == 1000000 and line["queries_per_step"] == nq and line["n_gpus"] == 1
+    if retrieval == "f16":
+        assert line["self_check"]["fp16_recall_at_k_vs_exact_f32"] >= 0.99 and line["self_check"]["queries_checked"] == 256
+    else:
+        assert line["self_check"]["lists_bit_identical_to_plain_exact_ranking"] is True
+
+
 def test_bench_starts_its_own_ranks_when_typed_without_a_launcher():
     """Literally `python3 bench.py --gpus 2 ...` (the form the driver types): the parent never touches the GPU, starts the two
     ranks as fresh processes through torch.distributed.run on 127.0.0.1 and relays rank 0's line.  With no workload flag the
