@@ -940,11 +940,12 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
                out_b, out_f64, partial, dblocks, nullptr, nullptr, K, 0, 0, 0.0, n_img};
     const int pm = prm.power_norm_weight == 1.0 ? 0 : (prm.power_norm_weight == 0.5 ? 1 : 2);
     const int nm = norm_mode == 2 ? 2 : (norm_mode == 0 ? 0 : 1);
-    // measurement variant (PVS_OPT_FISHER_SCALE = 1): one workgroup per image walks the dim blocks and divides the row itself.
-    // At configs[2] on one box: 25.3 ms against 24.2 ms for moments + scale pass (f32 rows), 29.9 against 27.0 (f64 rows) -- the
-    // moments kernel runs at 54 % of the f64 MFMA rate with its epilogue on the vector ALUs, so there is no idle time for the tail
-    // to hide in, and one workgroup's tail has 32 KB in flight where the scale pass has the whole chip's.
-    const bool fold = ctx->opt[PVS_OPT_FISHER_SCALE] == 1;
+    // With enough images to fill the chip at one workgroup per image, the workgroup walks the image's dim blocks and divides the
+    // row by its norm itself; otherwise (and with PVS_OPT_FISHER_SCALE = 1) one workgroup per (image, dim block) and a second pass.
+    // configs[2], alternating on one box (profiles/r03_fisher_scale_in_kernel.txt): 23.3 against 23.7 ms (f32 rows), 26.0 against
+    // 26.3 (f64 rows); with the 8-wave kernel of rounds 1-2 the in-kernel form lost (25.3 against 24.2).  Same bits either way.
+    const int scale_opt = ctx->opt[PVS_OPT_FISHER_SCALE];
+    const bool fold = scale_opt == 2 || (scale_opt == 0 && n_img >= 2 * (int64_t)ctx->num_cu);
     m.fold = fold ? 1 : 0;
     m.eps = prm.epsilon;
     folded = fold;

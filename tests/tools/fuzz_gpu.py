@@ -69,7 +69,11 @@ def case_fisher():
     order = float(rng.choice([2.0, 1.0]))
     g = ctx.gmm(w, mu, cov)
     packed, off = pvsim.pack_descriptors(descs, D, np.float32)
-    f = ctx.fisher_encode(g, packed, off, power=power, norm_order=order)
+    scale_opt = int(rng.integers(0, 3))        # where the rows are divided by their norm: chosen / second pass / inside the kernel
+    with ctx.option(pvsim._ffi.OPT_FISHER_SCALE, scale_opt):
+        f = ctx.fisher_encode(g, packed, off, power=power, norm_order=order)
+    if scale_opt:
+        assert np.array_equal(f, ctx.fisher_encode(g, packed, off, power=power, norm_order=order)), ("fisher scale forms differ", K, D, counts_, scale_opt)
     g.close()
     ref = orc.fisher_encode(descs, w, mu, cov, power=power, norm_order=order)
     assert np.allclose(f, ref, rtol=0, atol=2e-9), ("fisher", K, D, counts_, power, order, float(np.abs(f - ref).max()))
