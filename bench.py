@@ -520,10 +520,26 @@ def main():
     enc_all = torch.empty((world * per, L), dtype=torch.float32, device=dev) if need_f32_all else enc_loc
     inv_all = torch.empty((world * per,), dtype=torch.float32, device=dev) if multi else inv_loc
     enc16_loc = enc16_all = None
+    # Bounded query block on several GPUs (the N > 1 default): the QUERIES travel, the database stays.  Every rank all-gathers the
+    # ranks' query blocks (world x nqB rows: 4.3 GB at 65536 queries) instead of the database blocks (65.5 GB at 10^6 images),
+    # ranks all of them against its own database block, sends each owner its k candidates per query (all-to-all) and merges the
+    # `world` lists it receives for its own queries.  Same flop per rank, a fifteenth of the bytes on the links.  All-vs-all
+    # (queries = database) keeps the chunked database all-gather below.
+    nqB = min(per, max(1, args.total_queries // world)) if args.total_queries > 0 else per
+    travel = retr == "f16" and multi and args.total_queries > 0 and nqB * world < N
     if retr == "f16":
         enc16_loc = torch.empty((per, L), dtype=torch.float16, device=dev)
+        if n_loc < per:
+            enc16_loc[n_loc:].zero_()
         enc16_all = enc16_loc
-        if multi:
+        if travel:
+            q16_all = torch.empty((world, nqB, L), dtype=torch.float16, device=dev)
+            invq_all = torch.empty((world, nqB), dtype=torch.float32, device=dev)
+            part_idx = torch.full((world, nqB, k_top), -1, dtype=torch.int64, device=dev)
+            part_val = torch.full((world, nqB, k_top), float("-inf"), dtype=torch.float32, device=dev)
+            recv_idx, recv_val = torch.empty_like(part_idx), torch.empty_like(part_val)
+            enc16_all = None
+        elif multi:
             # the gathered fp16 corpus arrives in ROW CHUNKS of every rank's block (PVS_BENCH_XCHUNKS all-gathers instead of one),
             # so that the scoring of chunk c overlaps the transfer of chunk c + 1: [chunk][rank][rows of the chunk][L]
             x_chunks, x_pieces = pd.exchange_chunks(N, world, int(os.environ.get("PVS_BENCH_XCHUNKS", "4")))
@@ -532,8 +548,8 @@ def main():
     nq = n_loc if args.queries <= 0 else min(n_loc, args.queries)            # query rows of this rank (all of them by default)
     if args.total_queries > 0:                                               # strong scaling: the queries are shared out
         nq = min(n_loc, max(1, args.total_queries // world))
-    idx = torch.empty((max(n_loc, 1), k_top), dtype=torch.int64, device=dev)
-    val = torch.empty((max(n_loc, 1), k_top), dtype=torch.float32, device=dev)
+    idx = torch.empty((max(n_loc, nqB if args.total_queries > 0 else 0, 1), k_top), dtype=torch.int64, device=dev)
+    val = torch.empty((idx.shape[0], k_top), dtype=torch.float32, device=dev)
 
     if corpus1m:
         # BASELINE configs[3]: every image has 512 raw SIFT-like uint8 descriptors, generated on the device CHUNK BY CHUNK
@@ -621,7 +637,23 @@ def main():
 
     def retrieve(filtered_now):
         exchanged = exchange_begin() if (multi and retr != "f16") else (lambda: None)
-        if retr == "f16" and multi:
+        if travel:
+            to_exchange_stream()                             # the exchange stream waits for the encode, nothing later
+            comm.all_gather(inv_loc[:nqB], invq_all)
+            comm.all_gather(enc16_loc[:nqB], q16_all)
+            if n_loc > 0:                                    # this rank's own queries against its block while the others' arrive
+                ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nqB, enc16_loc.data_ptr(), n_loc, L, inv_loc.data_ptr(), inv_loc.data_ptr(),
+                                        k_top, lo, False, part_idx[rank].data_ptr(), part_val[rank].data_ptr())
+            from_exchange_stream()
+            for r in range(world):
+                if r == rank or n_loc <= 0:
+                    continue
+                ctx.cosine_topk_f16_dev(q16_all[r].data_ptr(), nqB, enc16_loc.data_ptr(), n_loc, L, invq_all[r].data_ptr(), inv_loc.data_ptr(),
+                                        k_top, lo, False, part_idx[r].data_ptr(), part_val[r].data_ptr())
+            a2a(recv_idx.view(-1), part_idx.view(-1))        # slab r of part_* goes to rank r; slab s of recv_* comes from rank s
+            a2a(recv_val.view(-1), part_val.view(-1))
+            ctx.topk_merge_dev(recv_idx.data_ptr(), recv_val.data_ptr(), world, nqB, k_top, idx.data_ptr(), val.data_ptr())
+        elif retr == "f16" and multi:
             # The rank's own block first, from its local copy, while the first chunk arrives; then, chunk by chunk, the rows of
             # every other rank as soon as that chunk's all-gather has finished (the exchange stream runs ahead: the compute
             # stream waits only for what had been queued there when it asked).  Every rank takes part in every collective,
@@ -734,6 +766,7 @@ def main():
                 torch.cuda.synchronize()
                 to_exchange_stream()
                 comm.all_gather(enc_loc, ref_db)
+                comm.all_gather(inv_loc, inv_all)            # (not gathered by the run itself when the queries travel)
                 from_exchange_stream()
                 barrier()
             else:
@@ -800,7 +833,10 @@ def main():
         "metric": "images/sec encoded + top-k retrieved, VLAD K256 RootSIFT",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         **({"exchange": "allgather over " + ("gloo (host-staged REHEARSAL)" if staged else "RCCL behind the C-ABI (" + pd.RcclComm.library() + ")"),
-            "exchange_overlaps_own_block": bool(overlap and not staged and retr in ("exact", "f16"))} if multi else {}),
+            "exchange_overlaps_own_block": bool(overlap and not staged and retr in ("exact", "f16")),
+            "exchange_plan": (f"queries travel: {world} x {nqB} fp16 query rows all-gathered ({world * nqB * L * 2 / 1e9:.2f} GB), every rank ranks them "
+                              f"against its own database block, k candidates per query back by all-to-all, merged by the owner" if travel else
+                              "database travels: every rank all-gathers all encoding blocks and ranks its own queries against them")} if multi else {}),
         **({"backend": "ONE-rank RCCL self-check of the multi-rank path: not a measurement"} if forced else {}),
         **({"backend": "gloo REHEARSAL (ranks share GPUs, host-staged collectives): not a measurement"} if staged else {}),
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

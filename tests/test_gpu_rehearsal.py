@@ -67,6 +67,18 @@ def test_one_rank_rccl_self_check(workload, retrieval):
     assert "RCCL self-check" in line["backend"] and "RCCL behind the C-ABI" in line["exchange"]
 
 
+@pytest.mark.parametrize("ranks,env", [(3, {"PVS_BENCH_BACKEND": "gloo"}), (1, {"PVS_BENCH_FORCE_DIST": "1"})], ids=["gloo-3-ranks", "rccl-1-rank"])
+def test_bounded_query_block_travels_instead_of_the_database(ranks, env):
+    """The N > 1 default (a bounded query block over a sharded corpus): the ranks all-gather their QUERY blocks, rank all of them
+    against their own database block, return k candidates per query by all-to-all and merge -- instead of all-gathering the
+    database.  20000 images, 3000 queries in all; recall@10 of every rank's lists against its exact fp32 ranking (asserted inside
+    bench.py on every rank), self-retrieval first."""
+    r, line = _run_bench(ranks, env, ["--workload", "corpus1m", "--steps", "1", "--warmup", "1", "--images", "20000", "--retrieval", "f16",
+                                      "--total-queries", "3000"])
+    assert line["exchange_plan"].startswith("queries travel") and line["queries_per_step"] == 3000 // ranks * ranks
+    assert line["self_check"]["fp16_recall_at_k_vs_exact_f32"] >= 0.99
+
+
 def test_corpus1m_single_gpu_filtered_equals_exact():
     """Single GPU, no launcher: the chunked corpus build + filtered retrieval, lists bit-identical to the all-pairs f32 GEMM."""
     from conftest import REPO
