@@ -533,11 +533,7 @@ def main():
             enc16_loc[n_loc:].zero_()
         enc16_all = enc16_loc
         if travel:
-            q16_all = torch.empty((world, nqB, L), dtype=torch.float16, device=dev)
-            invq_all = torch.empty((world, nqB), dtype=torch.float32, device=dev)
-            part_idx = torch.full((world, nqB, k_top), -1, dtype=torch.int64, device=dev)
-            part_val = torch.full((world, nqB, k_top), float("-inf"), dtype=torch.float32, device=dev)
-            recv_idx, recv_val = torch.empty_like(part_idx), torch.empty_like(part_val)
+            travel_bufs = [None]
             enc16_all = None
         elif multi:
             # the gathered fp16 corpus arrives in ROW CHUNKS of every rank's block (PVS_BENCH_XCHUNKS all-gathers instead of one),
@@ -638,21 +634,17 @@ def main():
     def retrieve(filtered_now):
         exchanged = exchange_begin() if (multi and retr != "f16") else (lambda: None)
         if travel:
-            to_exchange_stream()                             # the exchange stream waits for the encode, nothing later
-            comm.all_gather(inv_loc[:nqB], invq_all)
-            comm.all_gather(enc16_loc[:nqB], q16_all)
-            if n_loc > 0:                                    # this rank's own queries against its block while the others' arrive
-                ctx.cosine_topk_f16_dev(enc16_loc.data_ptr(), nqB, enc16_loc.data_ptr(), n_loc, L, inv_loc.data_ptr(), inv_loc.data_ptr(),
-                                        k_top, lo, False, part_idx[rank].data_ptr(), part_val[rank].data_ptr())
-            from_exchange_stream()
-            for r in range(world):
-                if r == rank or n_loc <= 0:
-                    continue
-                ctx.cosine_topk_f16_dev(q16_all[r].data_ptr(), nqB, enc16_loc.data_ptr(), n_loc, L, invq_all[r].data_ptr(), inv_loc.data_ptr(),
-                                        k_top, lo, False, part_idx[r].data_ptr(), part_val[r].data_ptr())
-            a2a(recv_idx.view(-1), part_idx.view(-1))        # slab r of part_* goes to rank r; slab s of recv_* comes from rank s
-            a2a(recv_val.view(-1), part_val.view(-1))
-            ctx.topk_merge_dev(recv_idx.data_ptr(), recv_val.data_ptr(), world, nqB, k_top, idx.data_ptr(), val.data_ptr())
+            def score16(q, n_q, db, n_db, inv_q, inv_db, k_, off_, merge_, i_, v_):
+                ctx.cosine_topk_f16_dev(q.data_ptr(), n_q, db.data_ptr(), n_db, L, inv_q.data_ptr(), inv_db.data_ptr(), k_, off_, merge_,
+                                        i_.data_ptr(), v_.data_ptr())
+
+            def travel_array(shape, dtype, fill):
+                dt_ = getattr(torch, dtype) if isinstance(dtype, str) else dtype
+                return torch.empty(shape, dtype=dt_, device=dev) if fill is None else torch.full(shape, fill, dtype=dt_, device=dev)
+
+            travel_bufs[0] = pd.retrieve_traveling_queries(
+                enc16_loc[:nqB], inv_loc[:nqB], enc16_loc, inv_loc, n_loc, lo, rank, world, k_top, comm, a2a, score16, ops.merge,
+                travel_array, idx, val, gather_begin=to_exchange_stream, gather_arrived=from_exchange_stream, bufs=travel_bufs[0])
         elif retr == "f16" and multi:
             # The rank's own block first, from its local copy, while the first chunk arrives; then, chunk by chunk, the rows of
             # every other rank as soon as that chunk's all-gather has finished (the exchange stream runs ahead: the compute

@@ -325,6 +325,53 @@ def retrieve_sharded(enc_loc, inv_loc, enc_all, inv_all, n_total: int, rank: int
     return n_loc
 
 
+def retrieve_traveling_queries(q_loc, inv_q_loc, db_loc, inv_db_loc, n_db_loc: int, db_offset: int, rank: int, world: int,
+                               k: int, comm, all_to_all: Callable, score_block: Callable, merge: Callable, new_array: Callable,
+                               idx, val, gather_begin: Callable | None = None, gather_arrived: Callable | None = None, bufs=None):
+    """A bounded block of queries per rank against the SHARDED database, without moving the database (eval.py:13-46: a few
+    query images against a large index).  The ranks all-gather their query blocks (world x nqB rows -- small), every rank ranks
+    ALL queries against its own database block with true global indices, returns each owner its k candidates per query in one
+    all-to-all and the owner merges the `world` lists it receives.  The result equals ranking the owner's queries against the
+    whole gathered database: a row's score does not depend on the panel it was computed in, and all lists are ordered
+    (score desc, index asc).
+
+    q_loc (nqB, L) / inv_q_loc (nqB,): this rank's query block, the same nqB on every rank (pad with any rows; the owner ignores
+    the lists of its padding).  db_loc / inv_db_loc: this rank's database block, n_db_loc real rows whose global indices start
+    at db_offset.  comm.all_gather(send, recv); all_to_all(out, inp) exchanges equal slabs (RcclComm.all_to_all);
+    score_block(q, n_q, db, n_db, inv_q, inv_db, k, col_offset, merge, idx, val); merge(idx_lists, val_lists, n_lists, nq, k,
+    idx, val) (DeviceOps.merge); new_array(shape, dtype, fill).  idx / val: (>= nqB, k) outputs.
+    gather_begin() / gather_arrived(): stream-ordering hooks around the all-gather (the rank's own queries are scored from the
+    local copy between the two, so the gather runs under that launch).  bufs: the tuple a previous call of the same shape
+    returned (its six work arrays are used again instead of new ones)."""
+    nqB, L = q_loc.shape[0], q_loc.shape[1]
+    if bufs is not None:
+        q_all, invq_all, part_i, part_v, recv_i, recv_v = bufs
+    else:
+        q_all = new_array((world * nqB, L), q_loc.dtype, None)
+        invq_all = new_array((world * nqB,), inv_q_loc.dtype, None)
+        part_i = new_array((world * nqB, k), "int64", -1)
+        part_v = new_array((world * nqB, k), "float32", float("-inf"))
+        recv_i = new_array((world * nqB, k), "int64", -1)
+        recv_v = new_array((world * nqB, k), "float32", float("-inf"))
+    if gather_begin is not None:
+        gather_begin()
+    comm.all_gather(inv_q_loc, invq_all)
+    comm.all_gather(q_loc, q_all)
+    if n_db_loc > 0:
+        score_block(q_loc, nqB, db_loc, n_db_loc, inv_q_loc, inv_db_loc, k, db_offset, False, part_i[rank * nqB:], part_v[rank * nqB:])
+    if gather_arrived is not None:
+        gather_arrived()
+    for r in range(world):
+        if r == rank or n_db_loc <= 0:
+            continue
+        score_block(q_all[r * nqB:], nqB, db_loc, n_db_loc, invq_all[r * nqB:], inv_db_loc, k, db_offset, False,
+                    part_i[r * nqB:], part_v[r * nqB:])
+    all_to_all(recv_i.reshape(-1), part_i.reshape(-1))      # slab r of part_* goes to rank r; slab s of recv_* comes from rank s
+    all_to_all(recv_v.reshape(-1), part_v.reshape(-1))
+    merge(recv_i.reshape(world, nqB, k), recv_v.reshape(world, nqB, k), world, nqB, k, idx, val)
+    return q_all, invq_all, part_i, part_v, recv_i, recv_v   # (the caller may hand them back to its pool)
+
+
 def device_score_block(ctx):
     """score_block for device arrays: one pvs_cosine_topk_dev call (GEMM panel + select, running-list merge)."""
 
@@ -527,6 +574,33 @@ class ShardedVLADIndex:
                                                        lambda shape, like: self.pool.empty(shape, like.dtype))
         else:
             self.enc_all, self.inv_all = self.enc_loc, self.inv_loc
+
+    def search(self, q, inv_q, k: int):
+        """This rank's block of queries (DevArray (nqB, L) float32 + (nqB,) 1/norm; the same nqB on every rank) against the whole
+        sharded index WITHOUT the exchange(): the query blocks travel, the encoded blocks stay (retrieve_traveling_queries).
+        -> (idx (nqB, k) int64 global image indices, val (nqB, k) float32), the same lists as topk() would give these rows."""
+        nqB = q.shape[0]
+        for b in getattr(self, "_search_bufs", ()):
+            self.pool.release(b)
+        idx = self.pool.full((max(nqB, 1), k), "int64", -1)
+        val = self.pool.full((max(nqB, 1), k), "float32", float("-inf"))
+        n_loc = self.hi - self.lo
+        if self.comm is None:
+            self.ctx.cosine_topk_dev(q.data_ptr(), nqB, self.enc_loc.data_ptr(), n_loc, q.shape[1], inv_q.data_ptr(),
+                                     self.inv_loc.data_ptr(), k, 0, False, idx.data_ptr(), val.data_ptr())
+            self._search_bufs = (idx, val)
+        else:
+            inv_db = self.inv_loc       # padding rows carry NaN (mask_padding in encode_local) and only n_loc rows are scored anyway
+            ops = DeviceOps(self.ctx, same_stream=True)
+
+            def new_array(shape, dtype, fill):
+                return self.pool.empty(shape, dtype) if fill is None else self.pool.full(shape, dtype, fill)
+
+            tmp = retrieve_traveling_queries(q, inv_q, self.enc_loc, inv_db, n_loc, self.lo, self.rank, self.world, k, self.comm,
+                                             self.comm.all_to_all, device_score_block(self.ctx), ops.merge, new_array, idx, val)
+            self._search_bufs = (idx, val) + tuple(tmp)
+        self.ctx.sync()
+        return idx[:nqB].numpy(), val[:nqB].numpy()
 
     def topk(self, k: int):
         n_loc = self.hi - self.lo

@@ -185,6 +185,62 @@ def test_symmetric_pair_scheme_gloo(tmp_path, world, n_total):
     np.testing.assert_allclose(np.concatenate([p["val"] for p in parts]), rval, atol=1e-6)
 
 
+def _travel_worker(rank, world, port, n_total, nqB, k, out_dir):
+    for p in (os.path.join(REPO, "python-visual-similarity_amd"), os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+        sys.path.insert(0, p)
+    from pvsim import distributed as pd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(77)
+    enc = rng.normal(size=(n_total, 36)).astype(np.float32)
+    enc[7] = enc[1]                                                   # a tie between rows of different blocks
+    lo, hi, block = pd.shard_range(n_total, world, rank)
+    db = torch.zeros((block, 36), dtype=torch.float32)
+    db[: hi - lo] = torch.from_numpy(enc[lo:hi])
+    inv_db = torch.ones((block,), dtype=torch.float32)
+    # this rank's queries: the first rows of its block (fewer than nqB on a short last block: the rest is padding)
+    nq = min(nqB, hi - lo)
+    q = torch.zeros((nqB, 36), dtype=torch.float32)
+    q[:nq] = db[:nq]
+    inv_q = torch.ones((nqB,), dtype=torch.float32)
+    comm = _GlooComm()
+    idx = torch.full((nqB, k), -1, dtype=torch.int64)
+    val = torch.full((nqB, k), float("-inf"), dtype=torch.float32)
+
+    def new_array(shape, dtype, fill):
+        dt = getattr(torch, dtype) if isinstance(dtype, str) else dtype
+        return torch.empty(shape, dtype=dt) if fill is None else torch.full(shape, fill, dtype=dt)
+
+    bufs = pd.retrieve_traveling_queries(q, inv_q, db, inv_db, hi - lo, lo, rank, world, k, comm, comm.all_to_all, _oracle_score_block,
+                                         _CpuOps().merge, new_array, idx, val)
+    first = (idx.clone(), val.clone())
+    pd.retrieve_traveling_queries(q, inv_q, db, inv_db, hi - lo, lo, rank, world, k, comm, comm.all_to_all, _oracle_score_block,
+                                  _CpuOps().merge, new_array, idx, val, bufs=bufs)              # work arrays used again
+    assert torch.equal(first[0], idx) and torch.equal(first[1], val)
+    np.savez(os.path.join(out_dir, f"t{rank}.npz"), idx=idx[:nq].numpy(), val=val[:nq].numpy(), lo=lo, nq=nq, enc=enc)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,nqB", [(2, 23, 4), (3, 20, 3), (4, 9, 3)])
+def test_bounded_query_blocks_travel_the_database_stays_gloo(tmp_path, world, n_total, nqB):
+    """retrieve_traveling_queries with REAL collectives (gloo all-gather of the query blocks, all-to-all of the candidate lists)
+    and CPU stand-in kernels: every rank's lists equal the single-process ranking of its queries against the whole corpus
+    ((4, 9, 3): a short last block and a rank without any rows)."""
+    import pvsim_oracle as orc
+    k = 4
+    port = 27100 + (os.getpid() % 1500) + world * 11 + n_total
+    mp.spawn(_travel_worker, args=(world, port, n_total, nqB, k, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"t{r}.npz") for r in range(world)]
+    enc = parts[0]["enc"]
+    ridx, rval = orc.topk(orc.cosine_similarity(enc, enc), k)
+    for p_ in parts:
+        lo, nq = int(p_["lo"]), int(p_["nq"])
+        assert np.array_equal(p_["idx"], ridx[lo:lo + nq])
+        np.testing.assert_allclose(p_["val"], rval[lo:lo + nq], atol=1e-6)
+
+
 def test_devarray_views_and_unique_id_bootstrap():
     """DevArray's first-axis views (the only tensor protocol the retrieval logic needs) and the socket hand-off of the
     128-byte communicator id between two processes (no GPU: the id is replaced by a byte pattern)."""

@@ -154,3 +154,36 @@ def test_one_rank_rccl_point_to_point_and_collectives_without_torch():
         comm.close()
         ctx.close()
         comm.close()                                               # closing after the context is a no-op, not a use after free
+
+
+def test_sharded_index_search_on_a_one_rank_rccl_communicator():
+    """ShardedVLADIndex.search (a block of queries against the sharded index; the queries travel, the index stays): the whole
+    path -- query all-gather, per-block ranking with global indices, candidate all-to-all, merge -- on a one-rank RCCL
+    communicator, no torch object anywhere; lists bit-identical to the all-vs-all topk() rows of the same images."""
+    import numpy as np
+    import pvsim
+    from conftest import REPO
+    from pvsim import distributed as pd, synth, pack_descriptors
+    from pvsim.engine import DESC_U8_ROOTSIFT
+    tables = np.load(os.path.join(REPO, "tests", "golden", "tables_k256_d128.npz"), allow_pickle=False)
+    ctx = pvsim.Context(0)
+    comm = pd.RcclComm(ctx, 1, 0, pd.new_unique_id())
+    try:
+        rng = np.random.default_rng(5)
+        imgs = [synth.sift_like(int(n), rng).astype(np.uint8) for n in rng.integers(40, 300, size=41)]
+        packed, off = pack_descriptors(imgs, 128, np.uint8)
+        cb = ctx.codebook(tables["centroids"])
+        pool = pd.DevicePool(ctx)
+        d_x = pool.empty(packed.shape, "uint8").upload(packed)
+        d_off = pool.empty(off.shape, "int64").upload(off)
+        index = pd.ShardedVLADIndex(ctx, cb, len(imgs), comm)
+        index.encode_local(d_x.ptr, DESC_U8_ROOTSIFT, d_off.ptr, int(off[-1]))
+        index.exchange()
+        idx_all, val_all = index.topk(5)
+        for _ in range(2):                                   # the second call reuses the pool's blocks
+            idx, val = index.search(index.enc_loc[:9], index.inv_loc[:9], 5)
+            assert np.array_equal(idx, idx_all[:9]) and np.array_equal(val.view(np.uint32), val_all[:9].view(np.uint32))
+        pool.close()
+    finally:
+        comm.close()
+        ctx.close()
