@@ -568,10 +568,22 @@ class ShardedVLADIndex:
             mask_padding(self.inv_loc, n_loc)
         return self.enc_loc
 
+    def _to_comm(self):
+        """The communicator may live on a context (= stream) of its own: its stream waits for this index's work ..."""
+        if self.comm is not None and self.comm.ctx is not self.ctx:
+            self.comm.ctx.wait_for(self.ctx)
+
+    def _from_comm(self):
+        """... and this index's stream for what has been queued on the communicator's."""
+        if self.comm is not None and self.comm.ctx is not self.ctx:
+            self.ctx.wait_for(self.comm.ctx)
+
     def exchange(self):
         if self.world > 1:
+            self._to_comm()
             self.enc_all, self.inv_all = gather_blocks(self.enc_loc, self.inv_loc, self.comm,
                                                        lambda shape, like: self.pool.empty(shape, like.dtype))
+            self._from_comm()
         else:
             self.enc_all, self.inv_all = self.enc_loc, self.inv_loc
 
@@ -596,8 +608,14 @@ class ShardedVLADIndex:
             def new_array(shape, dtype, fill):
                 return self.pool.empty(shape, dtype) if fill is None else self.pool.full(shape, dtype, fill)
 
+            def a2a(out, inp):
+                self._to_comm()
+                self.comm.all_to_all(out, inp)
+                self._from_comm()
+
             tmp = retrieve_traveling_queries(q, inv_q, self.enc_loc, inv_db, n_loc, self.lo, self.rank, self.world, k, self.comm,
-                                             self.comm.all_to_all, device_score_block(self.ctx), ops.merge, new_array, idx, val)
+                                             a2a, device_score_block(self.ctx), ops.merge, new_array, idx, val,
+                                             gather_begin=self._to_comm, gather_arrived=self._from_comm)
             self._search_bufs = (idx, val) + tuple(tmp)
         self.ctx.sync()
         return idx[:nqB].numpy(), val[:nqB].numpy()

@@ -166,8 +166,8 @@ def test_sharded_index_search_on_a_one_rank_rccl_communicator():
     from pvsim import distributed as pd, synth, pack_descriptors
     from pvsim.engine import DESC_U8_ROOTSIFT
     tables = np.load(os.path.join(REPO, "tests", "golden", "tables_k256_d128.npz"), allow_pickle=False)
-    ctx = pvsim.Context(0)
-    comm = pd.RcclComm(ctx, 1, 0, pd.new_unique_id())
+    ctx, ctx_x = pvsim.Context(0), pvsim.Context(0)         # compute stream, exchange stream (ordered by pvs_stream_wait inside the index)
+    comm = pd.RcclComm(ctx_x, 1, 0, pd.new_unique_id())
     try:
         rng = np.random.default_rng(5)
         imgs = [synth.sift_like(int(n), rng).astype(np.uint8) for n in rng.integers(40, 300, size=41)]
@@ -186,4 +186,5 @@ def test_sharded_index_search_on_a_one_rank_rccl_communicator():
         pool.close()
     finally:
         comm.close()
+        ctx_x.close()
         ctx.close()
