@@ -84,7 +84,7 @@ def parse():
                     help="fp16 products per (row, cluster) of the assignment prefilter: 3 = the product path; 2 / 1 = measurement "
                          "variants with a wider margin (more rows left to the exact kernel; same labels)")
     ap.add_argument("--fisher-scale", type=int, choices=[0, 1, 2], default=0,
-                    help="--workload fisher: PVS_OPT_FISHER_SCALE (0 default; 1 = norm division always as a second pass; 2 = always inside the moments kernel)")
+                    help="--workload fisher: PVS_OPT_FISHER_SCALE (0 / 1 = norm division as a second pass, the default; 2 = inside the moments kernel)")
     ap.add_argument("--fused", action="store_true", help="encode with the one-read fused kernel (PVS_OPT_VLAD_PATH = 3) instead of assign + aggregate")
     ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim", "learn", "corpus1m"], default=None,
                     help="default: config2 (BASELINE configs[1], the headline) with --gpus 1; corpus1m (configs[3]/[4]: 1M images "

@@ -60,9 +60,9 @@ typedef enum {
                                 /* otherwise; 1: always the radix-select kernel; 2: always the rounds; 3: always the threshold filter  */
   PVS_OPT_AGG_VARIANT = 3,      /* gather aggregate at D <= 128: 0 (default) chosen by rows per cluster; 1: eight waves per SIMD,     */
                                 /* batches of 4 rows (short images); 2: five waves, batches of 8 (long images).  Same bits.         */
-  PVS_OPT_FISHER_SCALE = 4,     /* division of a Fisher row by its norm: 0 (default) inside the moments kernel (one workgroup per image) */
-                                /* from 2 x (number of CUs) images per call on, a second pass over the rows below that; 1: always the    */
-                                /* second pass; 2: always inside the kernel.  Same bits.                                                  */
+  PVS_OPT_FISHER_SCALE = 4,     /* division of a Fisher row by its norm: 0 (default) and 1: a second pass over the rows; 2: inside the      */
+                                /* moments kernel (one workgroup per image; 1.6 % less time, 1.7 x the bytes beyond L2 at configs[2]).     */
+                                /* Same bits.                                                                                             */
   PVS_OPT_COUNT_ = 5
 } pvs_option;
 

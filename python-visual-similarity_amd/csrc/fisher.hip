@@ -940,12 +940,12 @@ static int fisher_batch(pvs_ctx* ctx, const pvs_gmm* g, const float* x, int ld, 
                out_b, out_f64, partial, dblocks, nullptr, nullptr, K, 0, 0, 0.0, n_img};
     const int pm = prm.power_norm_weight == 1.0 ? 0 : (prm.power_norm_weight == 0.5 ? 1 : 2);
     const int nm = norm_mode == 2 ? 2 : (norm_mode == 0 ? 0 : 1);
-    // With enough images to fill the chip at one workgroup per image, the workgroup walks the image's dim blocks and divides the
-    // row by its norm itself; otherwise (and with PVS_OPT_FISHER_SCALE = 1) one workgroup per (image, dim block) and a second pass.
-    // configs[2], alternating on one box (profiles/r03_fisher_scale_in_kernel.txt): 23.3 against 23.7 ms (f32 rows), 26.0 against
-    // 26.3 (f64 rows); with the 8-wave kernel of rounds 1-2 the in-kernel form lost (25.3 against 24.2).  Same bits either way.
-    const int scale_opt = ctx->opt[PVS_OPT_FISHER_SCALE];
-    const bool fold = scale_opt == 2 || (scale_opt == 0 && n_img >= 2 * (int64_t)ctx->num_cu);
+    // PVS_OPT_FISHER_SCALE = 2: one workgroup per image walks the image's dim blocks and divides the row by its norm itself (no
+    // second pass).  configs[2], alternating on one box (profiles/r03_fisher_scale_in_kernel.txt): 23.3 against 23.7 ms (f32 rows),
+    // 26.0 against 26.3 (f64 rows) -- but every dim block then re-reads the image's gamma rows from beyond L2 (63.7 + 16.7 GB
+    // fetched + written against 31.4 + 16.7 GB for moments + scale pass, profiles/r03_fisher_scale_pmc.txt): 1.6 % of the time for
+    // 1.7 x the bytes, so the default stays one workgroup per (image, dim block) with the image's blocks on one XCD, and a second pass.
+    const bool fold = ctx->opt[PVS_OPT_FISHER_SCALE] == 2;
     m.fold = fold ? 1 : 0;
     m.eps = prm.epsilon;
     folded = fold;

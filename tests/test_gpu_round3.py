@@ -262,11 +262,10 @@ def test_float64_wave_ranking_equals_the_lds_sort(gpu_ctx, nq, N, k):
 @pytest.mark.parametrize("kw", [dict(), dict(power=1.0, norm_order=1), dict(power=0.3, norm_order=3), dict(power=0.5, norm_order=np.inf)],
                          ids=["sqrt-l2", "p1-l1", "p0.3-l3", "sqrt-inf"])
 def test_fisher_rows_divided_inside_the_moments_kernel_equal_the_two_pass_form(gpu_ctx, kw):
-    """From 2 x (number of CUs) images per call on, one workgroup walks all dim blocks of its image and divides the row by its norm
-    itself instead of the separate scale pass (PVS_OPT_FISHER_SCALE pins either form).  Ragged images (empty ones included; D = 96
-    leaves a partial dim block; K = 41 leaves rows that are not 16-byte aligned) through the default, through both pinned forms
-    and in calls of 200 (below the threshold): the rows must agree bit for bit, and agree with the NumPy restatement
-    (fisher_vector.py:94-127) within the Fisher tolerance."""
+    """PVS_OPT_FISHER_SCALE = 2: one workgroup walks all dim blocks of its image and divides the row by its norm itself instead of
+    the separate scale pass.  Ragged images (empty ones included; D = 96 leaves a partial dim block; K = 41 leaves rows that are
+    not 16-byte aligned) through the default, through both pinned forms and in calls of 200: the rows must agree bit for bit,
+    and agree with the NumPy restatement (fisher_vector.py:94-127) within the Fisher tolerance."""
     from pvsim import pack_descriptors, _ffi
     FISHER_ATOL = 1e-9
     rng = np.random.default_rng(77)
