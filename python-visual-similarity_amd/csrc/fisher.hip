@@ -398,16 +398,19 @@ __global__ __launch_bounds__(PM_THREADS, 2) void gmm_posterior_mfma_kernel(PostM
 // ------------------------------------------------------------------------------------ K5 on fp64 MFMA (fused)
 // Per image:  S[k][c] = sum_i gamma[i][k] * Z[i][c]  (inner dimension n_i), then the gradients, the power norm and
 // this block's share of the global norm -- the raw sums never leave the registers.
-// Block = (image, 32 dims), 4 waves: wave wm owns cluster rows [64 wm, +64) and the 64 columns Z = [x_d (32) | x_d**2 (32)]
-// of dims d0 + [0, 32), so that the lane holding S1[k][d] (column tile ni) also holds S2[k][d] (tile ni + 2).
-// s0[k] = sum_i gamma[i][k] is summed by thread k from the staged gamma^T chunks (descriptor order).
-// Shape: the accumulators take 128 of a wave's 256 registers, so a CU holds 8 waves.  As ONE workgroup of 8 waves (round 1-2:
-// 64 dims, chunks of 16 descriptors, 104 KB of LDS) all of them sit in the same phase -- the MFMA loop (10.7 ms of pipe time at
-// configs[2]) and the epilogue (two fp64 square roots per output on the vector ALUs) ran one after the other: 19.7 ms, pipe 56 %
-// busy.  As TWO workgroups of 4 waves (chunks of 8 descriptors, 46 KB each) the phases of the two drift apart and one's
-// epilogue runs under the other's MFMA loop.  The dim blocks of an image are mapped to ONE XCD, next to each other in its
-// dispatch order, so that the image's gamma rows (400 KB at configs[2], read by every dim block) come from HBM once instead
-// of once per XCD (28.6 GB fetched for 6.6 GB of operands before).
+// Block = (image, 32 dims), 8 waves: wave wm owns cluster rows [32 wm, +32) (MM_MI = 2 row tiles of 16) and the 64 columns
+// Z = [x_d (32) | x_d**2 (32)] of dims d0 + [0, 32), so that the lane holding S1[k][d] (column tile ni) also holds S2[k][d]
+// (tile ni + 2).  s0[k] = sum_i gamma[i][k] is summed by thread k from the staged gamma^T chunks (descriptor order).
+// Shape, as measured at configs[2] (profiles/r03_fisher_moments_ablation.txt):
+//   rounds 1-2  one workgroup of 8 waves x (64 clusters x 64 columns) on 64 dims, chunks of 16, 104 KB LDS, 256 registers:
+//               2 waves per SIMD, all in the same phase                                                    19.6 ms, pipe 56 % busy
+//   round 3 (a) two workgroups of 4 such waves on 32 dims, chunks of 8, 46 KB each                         19.0 ms
+//           (b) 8 waves x (32 clusters x 64 columns): 64 accumulator registers, <= 128 in all, so TWO workgroups = 4 waves
+//               per SIMD share a CU                                                                        17.8 ms, pipe 60 % busy
+// fp64 vector instructions and fp64 MFMAs run on the same units, so the epilogue (35 fp64 instructions per output) adds to the
+// loop whatever the occupancy.  The dim blocks of an image are mapped to ONE XCD, next to each other in its dispatch order, so
+// that the image's gamma rows (400 KB at configs[2], read by every dim block) are shared in that XCD's L2 (23.0 GB fetched beyond
+// L2 for 6.6 GB of operands; 28.6 GB with 64-dim blocks dealt round-robin).
 struct MomMArgs {
   const float* X;
   int D, ld, K;
@@ -441,7 +444,8 @@ __device__ __forceinline__ void store_out(void* out, int f64, int64_t i, T v) {
   else static_cast<float*>(out)[i] = (float)v;
 }
 
-constexpr int MM_THREADS = 256, MM_DIMS = 32, MM_KC = 8, MM_KCP = MM_KC + 1;
+constexpr int MM_MI = 2;                                   // 16-cluster row tiles per wave
+constexpr int MM_THREADS = 64 * (256 / (16 * MM_MI)), MM_DIMS = 32, MM_KC = 8, MM_KCP = MM_KC + 1;
 
 // The fused epilogue is instantiated per (power, norm) case: with p and the norm order as run-time values every one of
 // its 64 unrolled outputs carried an inlined pow() (18k instructions, 110 KB of code -- twice the instruction cache --
@@ -468,8 +472,8 @@ __device__ __forceinline__ double nterm_t(double v, double p) {
 }
 
 // RAW = leave the sums as they are (one EM M-step's sufficient statistics per descriptor chunk) instead of the Fisher epilogue
-template <bool RAW, int PM = 2, int NM = 0, bool OUT64 = true>
-__global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomMArgs a) {
+template <bool RAW, int PM = 2, int NM = 0, bool OUT64 = true, bool FOLD = false>
+__global__ __launch_bounds__(MM_THREADS, 4) void fisher_moments_mfma_kernel(MomMArgs a) {
   // double-buffered chunks (global loads of chunk c+1 in flight during the MFMAs of chunk c)
   extern __shared__ __attribute__((aligned(16))) char mm_smem[];
   double* const la0 = reinterpret_cast<double*>(mm_smem);   // [2][256 * MM_KCP]  gamma^T chunk: [k][i]
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
   // a.fold (non-RAW, one workgroup per image; measurement variant, see fisher_batch): this workgroup walks all dim blocks of its
   // image, keeps the norm term of each (added in block order, exactly as fisher_scale_kernel adds the partials) and finally
   // divides its own outputs, in place of the separate scale pass.
-  const bool fold = !RAW && a.fold != 0;
+  constexpr bool fold = !RAW && FOLD;   // (a.fold says the same at run time: the launcher picks the instantiation)
   // Otherwise workgroup b runs on XCD b % 8 (round-robin dispatch), as that XCD's (b / 8)-th: images are dealt to the XCDs in
   // groups of 8 and an XCD walks the dim blocks of its image before it moves to the next group.
   int img, db_first, db_last;
@@ -507,31 +511,36 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
   const int n = (int)(a.offsets[img + 1] - row0);
   const int K = a.K, D = a.D;
   const int64_t L = (int64_t)K + 2 * (int64_t)K * D;
-  f64x4_t acc[4][4];
+  f64x4_t acc[MM_MI][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MM_MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f64x4_t{0.0, 0.0, 0.0, 0.0};
   double s0 = 0.0;
 
-  // staging: gamma: thread t takes cluster k = t of the chunk's 8 descriptors (consecutive threads -> consecutive clusters);
-  // Z: dim dd = t & 31 of descriptor t >> 5
-  const int gk = tid, zd = tid & 31, zi = tid >> 5;
-  double gv[MM_KC];
-  float zv;
+  // staging: gamma: thread t takes cluster k = t & 255 of the chunk's descriptors (t >> 8) + GS q (consecutive threads ->
+  // consecutive clusters); Z: the first 256 threads: dim dd = t & 31 of descriptor t >> 5
+  constexpr int GS = MM_THREADS / 256, GQ = MM_KC / GS;
+  const int gk = tid & 255, gi = tid >> 8, zd = tid & 31, zi = tid >> 5;
+  const bool zt = tid < 32 * MM_KC;
+  static_assert(32 * MM_KC <= MM_THREADS && MM_KC % GS == 0 && MM_KC % 4 == 0, "staging layout");
+  double gv[GQ];
+  float zv = 0.f;
   auto fetch = [&](int i0) {
 #pragma unroll
-    for (int q = 0; q < MM_KC; ++q)
-      gv[q] = (i0 + q < n && gk < K) ? a.resp[(row0 + i0 + q) * a.resp_ld + a.k0 + gk] : 0.0;
-    zv = (i0 + zi < n && dblk + zd < D) ? a.X[(row0 + i0 + zi) * a.ld + dblk + zd] : 0.f;
+    for (int q = 0; q < GQ; ++q)
+      gv[q] = (i0 + gi + GS * q < n && gk < K) ? a.resp[(row0 + i0 + gi + GS * q) * a.resp_ld + a.k0 + gk] : 0.0;
+    if (zt) zv = (i0 + zi < n && dblk + zd < D) ? a.X[(row0 + i0 + zi) * a.ld + dblk + zd] : 0.f;
   };
   auto stash = [&](int buf) {
     double* la = la0 + buf * (256 * MM_KCP);
     double* lb = lb0 + buf * (64 * MM_KCP);
 #pragma unroll
-    for (int q = 0; q < MM_KC; ++q) la[gk * MM_KCP + q] = gv[q];
-    lb[zd * MM_KCP + zi] = (double)zv;
-    lb[(zd + 32) * MM_KCP + zi] = (double)(zv * zv);   // np.power(descriptors, 2) in fp32 (fisher_vector.py:104)
+    for (int q = 0; q < GQ; ++q) la[gk * MM_KCP + gi + GS * q] = gv[q];
+    if (zt) {
+      lb[zd * MM_KCP + zi] = (double)zv;
+      lb[(zd + 32) * MM_KCP + zi] = (double)(zv * zv);   // np.power(descriptors, 2) in fp32 (fisher_vector.py:104)
+    }
   };
   if (n > 0) {
     fetch(0);
@@ -543,23 +552,25 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
     const bool more = i0 + MM_KC < n;
     if (more) fetch(i0 + MM_KC);
     const double* la = la0 + buf * (256 * MM_KCP);
+    if (tid < 256) {
 #pragma unroll
-    for (int ii = 0; ii < MM_KC; ++ii) s0 += la[tid * MM_KCP + ii];   // zeros past n; descriptor order
-    f64_chunk_mma<4, 4, MM_KC>(la, lb0 + buf * (64 * MM_KCP), wm * 64, 0, lane, acc);
+      for (int ii = 0; ii < MM_KC; ++ii) s0 += la[tid * MM_KCP + ii];   // zeros past n; descriptor order
+    }
+    f64_chunk_mma<MM_MI, 4, MM_KC>(la, lb0 + buf * (64 * MM_KCP), wm * (16 * MM_MI), 0, lane, acc);
     if (more) stash(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
-  s0s[tid] = s0;
+  if (tid < 256) s0s[tid] = s0;
   __syncthreads();
 
   if constexpr (RAW) {
     const int col = lane & 15, rq = lane >> 4;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MM_MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int k = wm * 64 + 16 * mi + 4 * r + rq;
+        const int k = wm * (16 * MM_MI) + 16 * mi + 4 * r + rq;
         if (k >= K) continue;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -584,10 +595,10 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
   const int col = lane & 15, rq = lane >> 4;
   const double dn = (double)(n > 0 ? n : 1), rdn = 1.0 / dn;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MM_MI; ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int k = wm * 64 + 16 * mi + 4 * r + rq;
+      const int k = wm * (16 * MM_MI) + 16 * mi + 4 * r + rq;
       const double pp_sum = s0s[k < K ? k : 0] * rdn;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
@@ -608,6 +619,7 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
           part = is_max ? fmax(part, fmax(t1, t2)) : part + (t1 + t2);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // one (mi, r) group at a time: with every group's table loads hoisted to the top the kernel spills at 128 registers
     }
   if (db == 0 && tid < K) {   // d_pi (fisher_vector.py:107,117)
     const double w = a.w[tid];
@@ -680,7 +692,10 @@ __global__ __launch_bounds__(MM_THREADS, 2) void fisher_moments_mfma_kernel(MomM
 constexpr size_t MM_LDS = (size_t)(2 * 256 * MM_KCP + 2 * 64 * MM_KCP + 256 + 8) * sizeof(double);
 template <bool RAW, int PM, int NM, bool OUT64>
 static int launch_moments(pvs_ctx* ctx, const MomMArgs& m) {
-  auto k = fisher_moments_mfma_kernel<RAW, PM, NM, OUT64>;
+  auto k = fisher_moments_mfma_kernel<RAW, PM, NM, OUT64, false>;
+  if constexpr (!RAW) {
+    if (m.fold) k = fisher_moments_mfma_kernel<RAW, PM, NM, OUT64, true>;
+  }
   PVS_TRY(ensure_lds(ctx, reinterpret_cast<const void*>(k), MM_LDS));
   // one workgroup per (image, dim block), images padded to groups of 8 (one per XCD); fold: one workgroup per image
   const int64_t nblk = m.fold ? m.n_img : (m.n_img + 7) / 8 * 8 * m.dblocks;
