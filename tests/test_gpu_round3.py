@@ -296,3 +296,49 @@ def test_fisher_rows_divided_inside_the_moments_kernel_equal_the_two_pass_form(g
         sel = [0, 1, 2, 3, 4, 300, N - 2]
         ref = orc.fisher_encode([imgs[i] for i in sel], w, mu, cov, **okw)
         np.testing.assert_allclose(one[sel], ref, rtol=0, atol=FISHER_ATOL)
+
+
+# ======================================================================================= a resident index for the retrieval functions
+class _LookupEncoder:
+    """encode(image) -> the vector stored for that "image" (a 1 x 1 integer id array): lets the eval functions run on given vectors."""
+
+    def __init__(self, vectors, ctx):
+        self.vectors, self.context = vectors, ctx
+
+    def encode(self, image):
+        return self.vectors[int(np.asarray(image).reshape(-1)[0])].reshape(1, -1)
+
+
+@pytest.mark.parametrize("dtype,nq", [(np.float32, 7), (np.float32, 640), (np.float64, 9)], ids=["f32-few", "f32-many(filtered)", "f64"])
+def test_device_index_gives_the_results_of_the_dict(gpu_ctx, dtype, nq):
+    """pvsim.index.DeviceIndex (the encoding map resident and normalised on the GPU) passed where eval.* take the dict
+    (pyvisim/eval.py:13-145): the same paths, scores (bit for bit), mAP and accuracy as with the plain dict, in float32 (plain and
+    filtered retrieval) and float64; Mapping behaviour of the index itself."""
+    from pvsim import eval as pe
+    from pvsim.index import DeviceIndex
+    rng = np.random.default_rng(11)
+    N, L = 900, 96
+    db = rng.standard_normal((N, L)).astype(dtype)
+    db[17] = db[3]                                              # a tie
+    paths = [f"img_{i:04d}.jpg" for i in range(N)]
+    labels = {p: int(i % 13) for i, p in enumerate(paths)}
+    enc_map = dict(zip(paths, db))
+    qv = (db[rng.integers(0, N, nq)] + 0.05 * rng.standard_normal((nq, L))).astype(dtype)
+    enc = _LookupEncoder(qv, gpu_ctx)
+    q_imgs = [np.array([[i]], dtype=np.int64) for i in range(nq)]
+    q_lab = [int(rng.integers(0, 13)) for _ in range(nq)]
+    index = DeviceIndex(enc_map, gpu_ctx)
+    try:
+        assert len(index) == N and list(index.keys()) == paths and np.array_equal(index[paths[5]], db[5]) and paths[7] in index
+        a = pe.retrieve_top_k_similar(q_imgs[0], enc_map, enc, k=6)
+        b = pe.retrieve_top_k_similar(q_imgs[0], index, enc, k=6)
+        assert [p for p, _ in a] == [p for p, _ in b]
+        assert np.array_equal(np.array([s for _, s in a]).view(np.uint8), np.array([s for _, s in b]).view(np.uint8))
+        for k in (5, None):
+            assert pe.top_k_map(q_imgs, q_lab, enc_map, labels, enc, k=k) == pe.top_k_map(q_imgs, q_lab, index, labels, enc, k=k)
+        assert pe.top_k_accuracy(q_imgs, q_lab, enc_map, labels, enc, k=3) == pe.top_k_accuracy(q_imgs, q_lab, index, labels, enc, k=3)
+        i1, v1 = pe._rank(qv, db, 10, gpu_ctx)
+        i2, v2 = index.rank(qv, 10)
+        assert np.array_equal(i1, i2) and np.array_equal(v1.view(np.uint8), v2.view(np.uint8)) and v2.dtype == dtype
+    finally:
+        index.close()

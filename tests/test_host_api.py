@@ -202,7 +202,7 @@ def test_eval_bookkeeping_against_golden(monkeypatch, tables):
             self.i += 1
             return v
 
-    def fake_rank(query_vecs, all_vectors, k, ctx=None):
+    def fake_rank(query_vecs, all_vectors, k, ctx=None, resident=None):
         kk = all_vectors.shape[0] if k is None else min(k, all_vectors.shape[0])
         return orc.topk(orc.cosine_similarity(query_vecs, all_vectors), kk)
 
