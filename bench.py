@@ -86,12 +86,14 @@ def parse():
     ap.add_argument("--fisher-scale", type=int, choices=[0, 1, 2], default=0,
                     help="--workload fisher: PVS_OPT_FISHER_SCALE (0 / 1 = norm division as a second pass, the default; 2 = inside the moments kernel)")
     ap.add_argument("--fused", action="store_true", help="encode with the one-read fused kernel (PVS_OPT_VLAD_PATH = 3) instead of assign + aggregate")
-    ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim", "learn", "corpus1m"], default=None,
+    ap.add_argument("--workload", choices=["config2", "fisher", "vlad512", "fp16sim", "learn", "corpus1m", "serve"], default=None,
                     help="default: config2 (BASELINE configs[1], the headline) with --gpus 1; corpus1m (configs[3]/[4]: 1M images "
                          "sharded over the ranks, fp16 exchange + retrieval, 65536 queries in all) with --gpus N > 1.  Side workloads (single GPU, same JSON shape, not the "
                          "headline): fisher = BASELINE configs[2] (Fisher D=512 K=256 n=196), vlad512 = the per-GPU share of "
                          "configs[3] (n=512 descriptors per image, encode only), fp16sim = configs[4] scaled to one GPU "
-                         "(N x N cosine on fp16 encodings + top-10)")
+                         "(N x N cosine on fp16 encodings + top-10), serve = ONE query image at a time through the class API "
+                         "(eval.retrieve_top_k_similar: encode + top-5) against the 8189-image index, resident (pvsim.index.DeviceIndex) and "
+                         "as the reference's plain dict")
     ap.add_argument("--retrieval", choices=["exact", "filtered", "f16", "f64"], default=None,
                     help="f64 (--workload fisher only) = float64 encodings scored and ranked in float64 on the f64 matrix pipe, the "
                          "reference's dtype for Fisher vectors.  exact = f32 MFMA GEMM over all pairs (the headline). filtered = the same top-k lists, bit for bit, "
@@ -301,6 +303,61 @@ def side_workload(args):
                                  "frac": round(byt / dt / 1e9 / 8000.0, 4), "traffic": None,
                                  "assign_executed_f16_TFLOPs": None if args.fused else round(3 * 2.0 * N * n * K_CLUSTERS * DIM / (st["assign"] * 1e-3) / 1e12, 1)},
                     "encode_algorithmic_GBps": round(byt / dt / 1e9, 1)})
+    elif args.workload == "serve":
+        # Latency, not throughput: pyvisim's interactive use (eval.py:13-46) -- one uploaded image, encode, rank against the index,
+        # k paths back.  Host descriptors in, host list out: PCIe and every launch are inside the timed call.
+        from pvsim import eval as pe, synth
+        from pvsim.encoders import VLADEncoder
+        from pvsim.features import Lambda
+        from pvsim.index import DeviceIndex
+        from pvsim.models import KMeansModel
+        raw, offsets = make_corpus(N, 1235, dev)
+        d_off = torch.from_numpy(offsets).to(dev)
+        desc = rootsift_torch(raw)
+        cb = ctx.codebook(tables["centroids"])
+        enc = torch.empty((N, K_CLUSTERS * DIM), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()                              # torch filled `desc` on its own stream
+        ctx.vlad_encode_dev(cb, desc.data_ptr(), DESC_F32, d_off.data_ptr(), N, int(offsets[-1]), enc.data_ptr())
+        ctx.sync()
+        db = enc.cpu().numpy()
+        paths = [f"img_{i:05d}.jpg" for i in range(N)]
+        enc_map = dict(zip(paths, db))
+        rng = np.random.default_rng(4)
+        q_ids = rng.integers(0, N, size=64)
+        q_raw = [raw[offsets[i]:offsets[i + 1]].cpu().numpy() for i in q_ids]        # the "images": raw SIFT-like uint8 descriptors
+        encoder = VLADEncoder(Lambda(lambda im: synth.rootsift(im.astype(np.float32)), DIM), kmeans_model=KMeansModel(tables["centroids"]),
+                              context=ctx)
+        index = DeviceIndex(enc_map, ctx)
+
+        def run(dataset, reps):
+            lat = []
+            for r in range(reps):
+                qi = r % len(q_raw)
+                t0 = time.perf_counter()
+                got = pe.retrieve_top_k_similar([q_raw[qi]], dataset, encoder, k=TOPK)
+                lat.append(time.perf_counter() - t0)
+                assert got[0][0] == paths[q_ids[qi]], f"the query image {paths[q_ids[qi]]} is not its own nearest neighbour: {got}"
+            return np.array(lat) * 1e3
+        run(index, max(args.warmup, 1) * 8)
+        lat = run(index, max(args.steps, 1) * 64)
+        lat_dict = run(enc_map, 4)
+        a_ = pe.retrieve_top_k_similar([q_raw[0]], enc_map, encoder, k=TOPK)
+        b_ = pe.retrieve_top_k_similar([q_raw[0]], index, encoder, k=TOPK)
+        assert a_ == b_, "resident index and plain dict disagree"
+        out.update({"metric": "queries/sec, one image at a time: RootSIFT + VLAD K256 encode + top-5 against a resident 8189-image index (class API, host in / host out)",
+                    "value": round(1e3 / float(np.median(lat)), 1), "unit": "queries/s", "ms_per_step": round(float(np.median(lat)), 4),
+                    "higher_is_better": True, "dtype": "f32", "scaling": "strong",
+                    "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p90": round(float(np.percentile(lat, 90)), 4),
+                                   "p99": round(float(np.percentile(lat, 99)), 4), "min": round(float(lat.min()), 4), "calls": int(lat.size)},
+                    "plain_dict_latency_ms": {"p50": round(float(np.median(lat_dict)), 2), "calls": int(lat_dict.size),
+                                              "what": "the reference's calling convention: the (N, L) matrix is rebuilt from the dict and uploaded on every call"},
+                    "same_result_as_plain_dict": True,
+                    "config": {"workload": f"{N}-image VLAD index ({db.nbytes / 1e9:.2f} GB float32) resident on the GPU; queries of {int(np.mean([len(q) for q in q_raw]))} descriptors on average",
+                               "K": K_CLUSTERS, "D": DIM, "topk": TOPK},
+                    "roofline": {"kernel": "latency-bound (one 1 x N similarity row: 1.07 GB read per query)", "bound": "hbm",
+                                 "achieved": round(db.nbytes / (float(np.median(lat)) * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(db.nbytes / (float(np.median(lat)) * 1e-3) / 1e9 / 8000.0, 4), "traffic": None}})
+        index.close()
     elif args.workload == "learn":
         # vocabulary training: one "step" = k-means++ seeding + 10 Lloyd iterations (K=256)
         # and 5 EM iterations of a K=256 diagonal GMM over args.images x 64 RootSIFT descriptors

@@ -833,6 +833,14 @@ static int cosine_topk_impl(pvs_ctx* ctx, const void* d_Q, int64_t nq, const voi
   // Ranking deeper than 1024 pages through complete rows, so the panel then spans all N columns.
   const bool deep = k > 1024;
   if (deep && (merge || N > (int64_t)1 << 28)) PVS_FAIL(PVS_ERR_UNSUPPORTED, "ranking depth %d needs a single panel", k);
+  // one or two queries (eval.retrieve_top_k_similar against a resident index): a 1 x N score row in ONE pass over the database at
+  // HBM speed instead of 128-row MFMA tiles with 127 idle rows; the same scores bit for bit (filter.hip)
+  if (!f16 && N <= ((int64_t)1 << 28) && cosine_dense_rows_eligible(static_cast<const float*>(d_Q), static_cast<const float*>(d_DB), nq, L)) {
+    float* row = nullptr;
+    PVS_TRY(ws_reserve(ctx, 2, (size_t)nq * N * sizeof(float), reinterpret_cast<void**>(&row)));
+    PVS_TRY(launch_cosine_dense_rows(ctx, static_cast<const float*>(d_Q), nq, static_cast<const float*>(d_DB), N, L, d_inv_q, d_inv_db, row, N));
+    return launch_topk(ctx, row, nq, N, N, k, col_offset, merge, d_idx, d_val);
+  }
   const int64_t NC = deep ? N : std::min<int64_t>(N, 32768);
   const int64_t QT = deep ? std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 28) / N))
                           : std::min<int64_t>(nq, 8192);

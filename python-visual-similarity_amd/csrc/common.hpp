@@ -222,6 +222,9 @@ int launch_cosine_f64(pvs_ctx* ctx, const double* A, int64_t M, const double* B,
 int launch_row_inv_norms_f64(pvs_ctx* ctx, const double* d_x, int64_t rows, int64_t L, double* d_inv);
 int launch_cosine_f64_dev(pvs_ctx* ctx, const double* A, int64_t M, const double* B, int64_t N, int64_t L, const double* inva,
                           const double* invb, double* out, int64_t ldo);
+bool cosine_dense_rows_eligible(const float* Q, const float* DB, int64_t nq, int64_t L);
+int launch_cosine_dense_rows(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L, const float* invq,
+                             const float* invdb, float* scores, int64_t ld);
 int launch_topk(pvs_ctx* ctx, const float* scores, int64_t nq, int64_t ncols, int64_t ld, int k,
                 int64_t col_offset, int merge, int64_t* d_idx, float* d_val);
 int launch_topk_merge(pvs_ctx* ctx, const int64_t* idx_lists, const float* val_lists, int n_lists, int64_t nq,

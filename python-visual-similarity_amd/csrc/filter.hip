@@ -129,25 +129,31 @@ struct RescoreArgs {
   const int* count;
   int cap, k;
   int64_t col_offset;
-};
+  int64_t dense_n, dense_ld;   // DENSE: every database row is a "candidate": workgroup (g, q) scores rows [16 g, 16 g + 16) of query q
+};                             //        into cand_val[q * dense_ld + row] (cand_idx, count, cap, k unused)
 
+// DENSE: the same chains for ALL rows of the database, one or two queries at a time -- a single query against a resident index is
+// a 1 x N row of scores: through the 128 x 128 MFMA tiles that is 127 wasted rows per tile (0.44 ms of matrix work at 8189 x 32768
+// for 1.07 GB of reads); here it is one pass over the database at HBM speed, and the scores are the MFMA kernel's, bit for bit.
+template <bool DENSE>
 __global__ __launch_bounds__(FLT_THREADS, 4) void filter_rescore_kernel(RescoreArgs a) {
   __shared__ float a_s[32][FLT_SK + 1];
   __shared__ float b_s[FLT_PASS][32][FLT_SK + 1];
   __shared__ float csum[FLT_PASS][32];
   const int tid = threadIdx.x;
   const int cand = tid >> 5, c = tid & 31;
-  const int64_t q = blockIdx.x;
-  const int cnt = a.count[q];
-  if (cnt > a.cap) return;   // overflow: the exact path redoes this query
+  const int64_t q = DENSE ? blockIdx.y : blockIdx.x;
+  const int64_t dense0 = DENSE ? (int64_t)blockIdx.x * FLT_PASS : 0;
+  const int cnt = DENSE ? (int)min((int64_t)FLT_PASS, a.dense_n - dense0) : a.count[q];
+  if (!DENSE && cnt > a.cap) return;   // overflow: the exact path redoes this query
   const int64_t L = a.L;
   const int64_t nchunks = (L + 1023) / 1024;
   const float* qrow = a.Q + q * L;
   for (int p0 = 0; p0 < cnt; p0 += FLT_PASS) {
     const int slot = p0 + cand;
     const bool valid = slot < cnt;
-    const int64_t off = ((int64_t)(slot / a.k) * a.nq + q) * a.k + slot % a.k;
-    const int64_t j = valid ? a.cand_idx[off] - a.col_offset : 0;
+    const int64_t off = DENSE ? q * a.dense_ld + dense0 + slot : ((int64_t)(slot / a.k) * a.nq + q) * a.k + slot % a.k;
+    const int64_t j = !valid ? 0 : (DENSE ? dense0 + slot : a.cand_idx[off] - a.col_offset);
     const int npass = min(FLT_PASS, cnt - p0);
     float tot = 0.f;
     // staging roles: thread t < 256 loads float4 #t of the query slab; every thread loads 8 float4 of the candidate slabs
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(FLT_THREADS, 4) void filter_rescore_kernel(RescoreA
       brow[u] = nullptr;
       if (cd < npass) {
         const int sl = p0 + cd;
-        brow[u] = a.DB + (a.cand_idx[((int64_t)(sl / a.k) * a.nq + q) * a.k + sl % a.k] - a.col_offset) * L;
+        brow[u] = a.DB + (DENSE ? dense0 + sl : a.cand_idx[((int64_t)(sl / a.k) * a.nq + q) * a.k + sl % a.k] - a.col_offset) * L;
       }
     }
     auto fetch = [&](int64_t r0, int s) {
@@ -235,6 +241,24 @@ __global__ void filter_scatter_lists_kernel(const int64_t* __restrict__ idx_src,
   }
 }
 
+
+// One or two queries against all N rows: scores[q][j] by the defined recurrence, one pass over the database (see filter_rescore_kernel<true>)
+bool cosine_dense_rows_eligible(const float* Q, const float* DB, int64_t nq, int64_t L) {
+  return nq >= 1 && nq <= 2 && L % 8 == 0 && L >= 8 && L <= (int64_t)8 * 1024 * 1024 && reinterpret_cast<uintptr_t>(Q) % 16 == 0 &&
+         reinterpret_cast<uintptr_t>(DB) % 16 == 0;
+}
+int launch_cosine_dense_rows(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L, const float* invq,
+                             const float* invdb, float* scores, int64_t ld) {
+  if (!cosine_dense_rows_eligible(Q, DB, nq, L)) PVS_FAIL(PVS_ERR_UNSUPPORTED, "dense row scoring: shape does not qualify");
+  if (N <= 0) return PVS_OK;
+  const int64_t groups = (N + FLT_PASS - 1) / FLT_PASS;
+  if (groups > 0x7fffffffLL) PVS_FAIL(PVS_ERR_UNSUPPORTED, "dense row scoring: too many rows");
+  RescoreArgs ra{Q, DB, nq, L, invq, invdb, nullptr, scores, nullptr, 0, 1, 0, N, ld};
+  ScopedTimer tm(ctx, T_GEMM);
+  hipLaunchKernelGGL(filter_rescore_kernel<true>, dim3((unsigned)groups, (unsigned)nq), dim3(FLT_THREADS), 0, ctx->stream, ra);
+  PVS_HIP(hipGetLastError());
+  return PVS_OK;
+}
 
 int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const float* DB, int64_t N, int64_t L,
                                 const float* invq, const float* invdb, int k, int64_t col_offset, int64_t* d_idx, float* d_val,
@@ -321,7 +345,7 @@ int launch_cosine_topk_filtered(pvs_ctx* ctx, const float* Q, int64_t nq, const 
     {
       ScopedTimer tm(ctx, T_RESCORE);
       RescoreArgs ra{Q + q0 * L, DB, qn, L, invq ? invq + q0 : nullptr, invdb, cidx, cval, cnt, cap, k, 0};
-      hipLaunchKernelGGL(filter_rescore_kernel, dim3((unsigned)qn), dim3(FLT_THREADS), 0, ctx->stream, ra);
+      hipLaunchKernelGGL(filter_rescore_kernel<false>, dim3((unsigned)qn), dim3(FLT_THREADS), 0, ctx->stream, ra);
     }
     PVS_HIP(hipGetLastError());
     // ---- 6. rank the candidates (same keys as the exact path); database indices get the caller's offset afterwards

@@ -342,3 +342,32 @@ def test_device_index_gives_the_results_of_the_dict(gpu_ctx, dtype, nq):
         assert np.array_equal(i1, i2) and np.array_equal(v1.view(np.uint8), v2.view(np.uint8)) and v2.dtype == dtype
     finally:
         index.close()
+
+
+# ======================================================================================= one or two queries: one pass over the database
+@pytest.mark.parametrize("N,L,k", [(8189, 512, 5), (300, 4096, 7), (70000, 64, 3), (33, 1032, 33), (5000, 24, 2000)])
+def test_one_or_two_queries_take_the_dense_row_kernel_with_the_same_scores(gpu_ctx, N, L, k):
+    """pvs_cosine_topk_dev with nq <= 2 scores the 1 x N row with the exact re-scoring kernel run densely over the whole database
+    (one pass at HBM speed) instead of 128 x 128 MFMA tiles: indices and scores must be the MFMA path's bit for bit -- compared
+    with the same queries ranked as rows of a 130-query call (which takes the GEMM), incl. a k-tile tail (L = 1032), several
+    chains (L = 4096), a duplicated row, k = N and a deep ranking (k = 2000)."""
+    rng = np.random.default_rng(N + L)
+    db = rng.standard_normal((N, L)).astype(np.float32)
+    db[N // 2] = db[1]
+    q = (db[rng.integers(0, N, 130)] + 0.1 * rng.standard_normal((130, L))).astype(np.float32)
+    q[0] = db[1]                                                # exact ties among the candidates of query 0
+    d_db, d_q = gpu_ctx.buffer(db.nbytes).upload(db), gpu_ctx.buffer(q.nbytes).upload(q)
+    d_invdb, d_invq = gpu_ctx.buffer(N * 4), gpu_ctx.buffer(130 * 4)
+    gpu_ctx.row_inv_norms_dev(d_db.ptr, N, L, d_invdb.ptr)
+    gpu_ctx.row_inv_norms_dev(d_q.ptr, 130, L, d_invq.ptr)
+    d_i, d_v = gpu_ctx.buffer(130 * k * 8), gpu_ctx.buffer(130 * k * 4)
+    gpu_ctx.cosine_topk_dev(d_q.ptr, 130, d_db.ptr, N, L, d_invq.ptr, d_invdb.ptr, k, 0, False, d_i.ptr, d_v.ptr)
+    ri, rv = d_i.download((130, k), np.int64), d_v.download((130, k), np.float32)
+    for nq in (1, 2):
+        gpu_ctx.cosine_topk_dev(d_q.ptr, nq, d_db.ptr, N, L, d_invq.ptr, d_invdb.ptr, k, 0, False, d_i.ptr, d_v.ptr)
+        gi, gv = d_i.download((nq, k), np.int64), d_v.download((nq, k), np.float32)
+        assert np.array_equal(gi, ri[:nq]) and np.array_equal(gv.view(np.uint32), rv[:nq].view(np.uint32))
+    ref = orc.cosine_similarity(q[:2], db)
+    np.testing.assert_allclose(rv[:2], -np.sort(-ref, axis=1)[:, :k], rtol=0, atol=3e-6)
+    for b in (d_db, d_q, d_invdb, d_invq, d_i, d_v):
+        b.free()
