@@ -358,6 +358,24 @@ def side_workload(args):
                                  "achieved": round(db.nbytes / (float(np.median(lat)) * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                  "frac": round(db.nbytes / (float(np.median(lat)) * 1e-3) / 1e9 / 8000.0, 4), "traffic": None}})
         index.close()
+        if not args.no_cpu_baseline:
+            # the reference's procedure for ONE uploaded image (eval.py:13-46), restated in NumPy: RootSIFT -> predict -> residual loop ->
+            # normalise; rebuild the matrix from the dict; cosine against the whole database (re-normalised, as sklearn does); argsort
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            import pvsim_oracle as orc
+            cen = np.asarray(tables["centroids"], dtype=np.float32)
+            t_cpu = []
+            for qi in range(3):
+                t0 = time.perf_counter()
+                v = orc.vlad_encode([synth.rootsift(q_raw[qi].astype(np.float32))], cen)
+                allv = np.array(list(enc_map.values()))
+                sc = orc.cosine_similarity(v, allv)[0]
+                top = np.argsort(-sc)[:TOPK]
+                t_cpu.append(time.perf_counter() - t0)
+                assert paths[int(top[0])] == paths[q_ids[qi]]
+            out["cpu_baseline"] = {"value": round(1.0 / float(np.median(t_cpu)), 2), "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"NumPy restatement of the reference's per-query procedure (oracle/pvsim_oracle.py, BLAS threads as configured): "
+                                             f"3 queries against the same {N}-image database, median {float(np.median(t_cpu)) * 1e3:.0f} ms per query"}
     elif args.workload == "learn":
         # vocabulary training: one "step" = k-means++ seeding + 10 Lloyd iterations (K=256)
         # and 5 EM iterations of a K=256 diagonal GMM over args.images x 64 RootSIFT descriptors
