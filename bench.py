@@ -83,6 +83,9 @@ def parse():
     ap.add_argument("--prefilter-products", type=int, choices=[1, 2, 3], default=3,
                     help="fp16 products per (row, cluster) of the assignment prefilter: 3 = the product path; 2 / 1 = measurement "
                          "variants with a wider margin (more rows left to the exact kernel; same labels)")
+    ap.add_argument("--prefilter-16x16", action="store_true",
+                    help="assignment prefilter on v_mfma_f32_16x16x32_f16 (PVS_OPT_ASSIGN_PREFILTER = 4: measurement variant, 8-10 %% slower); "
+                         "same labels")
     ap.add_argument("--fisher-scale", type=int, choices=[0, 1, 2], default=0,
                     help="--workload fisher: PVS_OPT_FISHER_SCALE (0 / 1 = norm division as a second pass, the default; 2 = inside the moments kernel)")
     ap.add_argument("--fused", action="store_true", help="encode with the one-read fused kernel (PVS_OPT_VLAD_PATH = 3) instead of assign + aggregate")
@@ -271,6 +274,9 @@ def side_workload(args):
         if args.prefilter_products != 3:
             from pvsim import _ffi
             ctx.set_option(_ffi.OPT_ASSIGN_PREFILTER, {2: 2, 1: 3}[args.prefilter_products])
+        elif args.prefilter_16x16:
+            from pvsim import _ffi
+            ctx.set_option(_ffi.OPT_ASSIGN_PREFILTER, 4)
         from pvsim import synth
         proto = torch.from_numpy(synth.sift_prototypes().astype(np.float32)).to(dev)
         raw = torch.empty((N * n, DIM), dtype=torch.uint8, device=dev)
@@ -576,6 +582,9 @@ def main():
     if args.prefilter_products != 3:
         from pvsim import _ffi
         ctx.set_option(_ffi.OPT_ASSIGN_PREFILTER, {2: 2, 1: 3}[args.prefilter_products])
+    elif args.prefilter_16x16:
+        from pvsim import _ffi
+        ctx.set_option(_ffi.OPT_ASSIGN_PREFILTER, 4)
 
     # ---- corpus, sharded by image: rank r owns images [lo, hi)
     N = args.images

@@ -53,7 +53,8 @@ typedef enum {
  * tests and benchmarks can pin one of several implementations that must agree bit for bit. */
 typedef enum {
   PVS_OPT_ASSIGN_PREFILTER = 0, /* 1 (default): fp16 MFMA prefilter (three products) + exact pass on near ties; 0: exact f32 MFMA kernel   */
-                                /* only; 2 / 3: measurement variants with two / one fp16 product(s) and the wider margin that goes with them */
+                                /* only; 2 / 3: measurement variants with two / one fp16 product(s) and the wider margin that goes with them; */
+                                /* 4: three products on v_mfma_f32_16x16x32_f16 (D = 128, 128 < K <= 256: measurement variant, same lists)   */
   PVS_OPT_VLAD_PATH = 1,        /* 0 (default) and 1: assign + gather aggregate (two reads of the descriptors); 2: assign +        */
                                 /* streaming aggregate; 3: fused one-read kernel (D = 128, 128 < K <= 256; error otherwise)        */
   PVS_OPT_TOPK_SELECT_ONLY = 2, /* top-k kernel for k <= 16: 0 (default) threshold filter on panels of >= 4096 columns, k rounds         */

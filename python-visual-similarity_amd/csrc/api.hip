@@ -217,7 +217,7 @@ PVS_EXPORT int pvs_device_name(pvs_ctx* ctx, char* buf, size_t buflen) {
 PVS_EXPORT int pvs_set_option(pvs_ctx* ctx, int option, int value) {
   PVS_NEED(ctx, "ctx");
   if (option < 0 || option >= PVS_OPT_COUNT_) PVS_FAIL(PVS_ERR_INVALID, "unknown option %d", option);
-  const int hi = (option == PVS_OPT_VLAD_PATH || option == PVS_OPT_TOPK_SELECT_ONLY || option == PVS_OPT_ASSIGN_PREFILTER) ? 3 : ((option == PVS_OPT_AGG_VARIANT || option == PVS_OPT_FISHER_SCALE) ? 2 : 1);
+  const int hi = option == PVS_OPT_ASSIGN_PREFILTER ? 4 : (option == PVS_OPT_VLAD_PATH || option == PVS_OPT_TOPK_SELECT_ONLY) ? 3 : ((option == PVS_OPT_AGG_VARIANT || option == PVS_OPT_FISHER_SCALE) ? 2 : 1);
   if (value < 0 || value > hi) PVS_FAIL(PVS_ERR_INVALID, "option %d: value %d out of range 0..%d", option, value, hi);
   ctx->opt[option] = value;
   return PVS_OK;

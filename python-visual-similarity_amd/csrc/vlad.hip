@@ -213,6 +213,7 @@ struct Assign16Args {
   float2* rowstat;               // uint8 rows: (row sum + 1e-7, its reciprocal) per descriptor for the aggregate pass, or null
   unsigned long long* stamps;    // diagnostic build (DIAG) only: [16] cycle totals over all workgroups, see pvs_fused_profile
   int nprod;                     // fp16 products per (row, cluster): 3 (product path), 2 or 1 (measurement variants)
+  int shape16;                   // != 0: assign16x_kernel (v_mfma_f32_16x16x32_f16) where its shape qualifies (measurement variant)
 };
 
 // STEPS: the number of 16-dim k-steps when it is known at compile time (8 for D_pad16 = 128), 0 = read it from the arguments.
@@ -636,6 +637,335 @@ __global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16_kernel(Assign16Arg
   if (threadIdx.x == 0) a.amb_count[blockIdx.x] = s_count;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// assign16x_kernel: the prefilter of the shape the benchmarks use (D = 128, 128 < K <= 256, 16-byte aligned rows) on
+// v_mfma_f32_16x16x32_f16 -- a MEASUREMENT VARIANT (pvs_set_option(PVS_OPT_ASSIGN_PREFILTER, 4)).  Same products, same order per
+// (row, cluster) element (cl.xh, ch.xl, ch.xh per 32-dim step, then the three pieces of -|c|^2/2), same margin, same lists for the
+// exact kernel as assign16_kernel; what changes is the instruction shape (on the fp16 GEMM the 16 x 16 x 32 shape was worth 6-8 %
+// through the clock the part holds).  Here it is 8-10 % SLOWER than the 32 x 32 x 16 kernel (profiles/r03_prefilter_16x16.txt:
+// vlad512 assign 3.92 against 3.55 ms, headline 2.48 against 2.29 ms): twice the MFMA instructions for the same flop, four instead
+// of two -|c|^2/2 instructions per group, and every per-descriptor step of the tail done for two descriptors per lane.
+//   A operand = 16 clusters x 32 dims from the LDS tables: lane (i = lane & 15, g = lane >> 4) reads the 8 halfs at position
+//     32 s + 8 g of cluster row i -- in the tables' stored order that is dims 16 t + {4h .. 4h+3, 8+4h .. 8+4h+3}, t = 2 s + (g >> 1),
+//     h = g & 1;
+//   B operand = 16 descriptors x 32 dims from registers: lane (j = lane & 15, g) holds the same dims of descriptors j (fragment 0)
+//     and 16 + j (fragment 1) of the wave's 32;
+//   C: lane (j, q = lane >> 4) holds clusters 4 q .. 4 q + 3 of the tile for descriptor j: the argmin is lane-local over tiles and
+//     finishes with two exchanges among the four q-lanes of a descriptor.
+// Clusters go through in 8 groups of 32 (two tiles x two fragments x 4 registers = 16 accumulator registers, two sets alternating);
+// the selection over a group runs under the MFMAs of the next.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int KIND, int NP = 3>
+__global__ __launch_bounds__(ASSIGN_THREADS, 2) void assign16x_kernel(Assign16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned int s_count;
+  constexpr int CB = 256, stride = 128 + 8;
+  _Float16* lds_h = reinterpret_cast<_Float16*>(smem);
+  _Float16* lds_l = lds_h + CB * stride;
+  float* lds_n = reinterpret_cast<float*>(lds_l + CB * stride);    // (layout shared with assign16_kernel; not read here)
+  _Float16* lds_k = reinterpret_cast<_Float16*>(lds_n + CB);       // [CB][4]: the -|c|^2/2 pieces
+  constexpr bool LUT = KIND == PVS_DESC_U8_ROOTSIFT;
+  uint32_t* lds_t = reinterpret_cast<uint32_t*>(lds_k + 4 * CB);   // [256] uint8 rows: sqrt(raw) as an fp16 pair
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t nblocks = (a.total + ASSIGN_ROWS - 1) / ASSIGN_ROWS;
+
+  for (int idx = threadIdx.x; idx < 2 * CB * 16; idx += ASSIGN_THREADS) {
+    const int r = idx >> 4, c8 = idx & 15;      // r < 2 CB: hi rows then lo rows
+    *reinterpret_cast<uint4*>(lds_h + r * stride + 8 * c8) = *reinterpret_cast<const uint4*>(a.C16 + (int64_t)r * 128 + 8 * c8);
+  }
+  for (int idx = threadIdx.x; idx < CB; idx += ASSIGN_THREADS)
+    *reinterpret_cast<uint2*>(lds_k + 4 * idx) = *reinterpret_cast<const uint2*>(a.cnk + 4 * idx);
+  if constexpr (LUT) {
+    if (threadIdx.x < 256) {
+      const float sv = sqrtf((float)threadIdx.x);
+      const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+      lds_t[threadIdx.x] = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+    }
+  }
+  if (threadIdx.x == 0) s_count = 0u;
+  __syncthreads();
+  const float sqrt_d = sqrtf((float)a.D);
+  int64_t* const my_rows = a.amb_rows + (int64_t)blockIdx.x * a.cap;
+  // the dims this lane holds of every 32-dim step s: 16 t + 4 h + {0..3} and 16 t + 8 + 4 h + {0..3}, t = 2 s + (g >> 1), h = g & 1
+  const int dlane = 16 * (g >> 1) + 4 * (g & 1);
+
+  // rows of the NEXT block are requested before this block's MFMA phase and land under it (unconditional loads: a row past the end
+  // reads the last row instead, its result is not stored)
+  float xf[2][4][8];
+  uint32_t xw[2][4][2];
+  auto request_rows = [&](int64_t blk_) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      int64_t r = blk_ * ASSIGN_ROWS + wave * 32 + 16 * f + j;
+      r = r < a.total ? r : a.total - 1;
+      if constexpr (LUT) {
+        const uint8_t* pr = static_cast<const uint8_t*>(a.X) + r * a.ld + dlane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          xw[f][s][0] = *reinterpret_cast<const uint32_t*>(pr + 32 * s);
+          xw[f][s][1] = *reinterpret_cast<const uint32_t*>(pr + 32 * s + 8);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float4 v0 = load4<KIND>(a.X, r, a.ld, 32 * s + dlane);
+          const float4 v1 = load4<KIND>(a.X, r, a.ld, 32 * s + dlane + 8);
+          xf[f][s][0] = v0.x; xf[f][s][1] = v0.y; xf[f][s][2] = v0.z; xf[f][s][3] = v0.w;
+          xf[f][s][4] = v1.x; xf[f][s][5] = v1.y; xf[f][s][6] = v1.z; xf[f][s][7] = v1.w;
+        }
+      }
+    }
+  };
+  if (blockIdx.x < nblocks) request_rows(blockIdx.x);
+
+  // ping-pong: waves 0-3 / 4-7 (one of each per SIMD); group 1 runs one barrier behind group 0, so that on every SIMD one wave
+  // feeds the matrix pipe while the other does its vector work.  All waves run the same number of blocks: the barrier counts match.
+  const bool pp_g1 = wave >= ASSIGN_THREADS / 128;
+  if (pp_g1) __builtin_amdgcn_s_barrier();
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    f16x8_t xh[2][4], xl[2][4];
+    float nx[2], lut_sd[2] = {1.f, 1.f};
+    int x_shift[2] = {0, 0};
+    bool finite[2], rvalid[2];
+    _Float16 lut_f1[2] = {(_Float16)0.f, (_Float16)0.f}, lut_f2[2] = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int64_t row = blk * ASSIGN_ROWS + wave * 32 + 16 * f + j;
+      rvalid[f] = row < a.total;
+      if constexpr (LUT) {
+        unsigned ssum = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          ssum = __builtin_amdgcn_sad_u8(xw[f][s][0], 0u, ssum);
+          ssum = __builtin_amdgcn_sad_u8(xw[f][s][1], 0u, ssum);
+        }
+        ssum += __shfl_xor(ssum, 16, 64);
+        ssum += __shfl_xor(ssum, 32, 64);
+        const float sf = (float)ssum, dd = sf + 1e-7f;
+        if (a.rowstat != nullptr && g == 0 && rvalid[f]) a.rowstat[row] = make_float2(dd, 1.0f / dd);   // = RootsiftRow(s), bit for bit
+        lut_sd[f] = sqrtf(dd);
+        const float ff = ldexpf(lut_sd[f], a.cn_e1);
+        lut_f1[f] = (_Float16)ff;
+        lut_f2[f] = (_Float16)(ff - (float)lut_f1[f]);
+        finite[f] = ff >= 0.125f && ff <= 32768.f;      // f1, f2 normal fp16 numbers; all-zero rows go to the exact kernel
+        nx[f] = sqrtf(sf) * 1.0001f;                    // |T| = sqrt(sum of the raw row), exactly
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          uint32_t hw[4], lw[4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) {
+              const uint32_t w = xw[f][s][i];
+              const uint32_t e0 = lds_t[(w >> (16 * pq)) & 0xffu], e1 = lds_t[(w >> (16 * pq + 8)) & 0xffu];
+              hw[2 * i + pq] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);   // hi(e0) | hi(e1) << 16
+              lw[2 * i + pq] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);   // lo(e0) | lo(e1) << 16
+            }
+          xh[f][s] = __builtin_bit_cast(f16x8_t, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+          xl[f][s] = __builtin_bit_cast(f16x8_t, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+        }
+      } else {
+        float n2 = 0.f, amax = 0.f, rs_r = 0.f;
+        if constexpr (DescTraits<KIND>::rootsift) {   // see assign16_kernel: y' = v_sqrt(raw / d) within 2^-21 of the exact element
+          float sm = 0.f, rmax = 0.f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              sm += xf[f][s][q];
+              rmax = fmaxf(rmax, xf[f][s][q]);
+            }
+          sm += __shfl_xor(sm, 16, 64);
+          sm += __shfl_xor(sm, 32, 64);
+          rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
+          rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+          rs_r = 1.0f / (sm + 1e-7f);
+          n2 = sm * rs_r * 1.0001f;
+          amax = __builtin_amdgcn_sqrtf(rmax * rs_r) * 1.0001f;
+          if (!(sm >= 0.f) || !(rmax * rs_r <= 3.0e38f)) n2 = NAN;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              n2 = fmaf(xf[f][s][q], xf[f][s][q], n2);
+              amax = fmaxf(amax, fabsf(xf[f][s][q]));
+            }
+          n2 += __shfl_xor(n2, 16, 64);
+          n2 += __shfl_xor(n2, 32, 64);
+          amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+          amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        }
+        nx[f] = sqrtf(n2) * 1.0001f;
+        int ex = 13;
+        if (amax > 0.f) (void)frexpf(amax, &ex);
+        x_shift[f] = 13 - ex;
+        finite[f] = nx[f] <= 3.0e38f;   // false for NaN too
+        if (x_shift[f] > 40 || x_shift[f] < -40) { finite[f] = false; x_shift[f] = 0; }
+        if (x_shift[f] + a.cn_e1 < -14 || x_shift[f] + a.cn_e1 > 15) finite[f] = false;   // the row scale enters the -|c|^2/2 step as a normal fp16 number
+        const float xs = ldexpf(1.f, x_shift[f]);
+        const float rs_rs = rs_r * xs * xs;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float v;
+            if constexpr (DescTraits<KIND>::rootsift) v = __builtin_amdgcn_sqrtf(xf[f][s][q] * rs_rs);
+            else v = xf[f][s][q] * xs;
+            const _Float16 hi = (_Float16)v;
+            xh[f][s][q] = hi;
+            xl[f][s][q] = (_Float16)(v - (float)hi);
+          }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);      // after the conversion: the old row registers are dead, the new ones not yet live
+    if (blk + gridDim.x < nblocks) request_rows(blk + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+
+    // ---- 8 groups of 32 clusters: s = 2^(shifts) (x.c - |c|^2/2) on the matrix pipe, the LARGEST s is the nearest centre
+    f32x4v acc[2][2][2];                    // [set][tile][fragment]
+    f16x8_t fh[2][2], fl[2][2];
+    // per-lane table addresses; a group is 32 cluster rows further on (the group loop stays a loop: with all 32 units unrolled the
+    // compiler kept one address register per far offset and spilled them)
+    const _Float16* const ph = lds_h + j * stride + 8 * g;
+    const _Float16* const pl = lds_l + j * stride + 8 * g;
+    auto fetch = [&](int buf, int gr, int s) {
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile) {
+        fh[buf][tile] = *reinterpret_cast<const f16x8_t*>(ph + (32 * gr + 16 * tile) * stride + 32 * s);
+        fl[buf][tile] = *reinterpret_cast<const f16x8_t*>(pl + (32 * gr + 16 * tile) * stride + 32 * s);
+      }
+    };
+    float best[2] = {-INFINITY, -INFINITY}, second[2] = {-INFINITY, -INFINITY};
+    int bidx[2] = {0, 0};
+    auto select4 = [&](int ab, int gr, int part) {   // part = 2 tile + fragment: the 4 clusters 32 gr + 16 tile + 4 q + e of this lane
+      const int tile = part >> 1, f = part & 1;
+      const int r0 = 32 * gr + 16 * tile;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc[ab][tile][f][e];
+        const bool gt = v > best[f];           // ascending cluster order, strict '>': the first maximum stays
+        second[f] = __builtin_amdgcn_fmed3f(best[f], second[f], v);
+        best[f] = gt ? v : best[f];
+        bidx[f] = gt ? (r0 + e) : bidx[f];     // the lane's 4 q is added after the loop
+      }
+    };
+    f16x8_t cnb[2];                            // B fragment of the -|c|^2/2 step: the row's 2^(x_shift + e1) in k-slots 0..2 of the g = 0 lanes
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cnb[f][q] = (_Float16)0.f;
+      if constexpr (LUT) {   // six exact products: (three pieces of -|c|^2/2) x (two pieces of sqrt(d) 2^cn_e1)
+        if (g == 0 && finite[f]) { cnb[f][0] = lut_f1[f]; cnb[f][1] = lut_f2[f]; cnb[f][2] = lut_f1[f]; cnb[f][3] = lut_f2[f]; cnb[f][4] = lut_f1[f]; cnb[f][5] = lut_f2[f]; }
+      } else {
+        const _Float16 pw = (g == 0 && finite[f]) ? (_Float16)ldexpf(1.f, x_shift[f] + a.cn_e1) : (_Float16)0.f;
+        cnb[f][0] = pw; cnb[f][1] = pw; cnb[f][2] = pw;
+      }
+    }
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    fetch(0, 0, 0);
+#pragma unroll 1
+    for (int gp = 0; gp < 4; ++gp) {
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab) {         // group gr = 2 gp + ab accumulates in set ab
+        const int gr = 2 * gp + ab;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int buf = s & 1;
+          if (s < 3) fetch(buf ^ 1, gr, s + 1);
+          else if (gr < 7) fetch(buf ^ 1, gr + 1, 0);
+          __builtin_amdgcn_sched_barrier(0);     // the fetch stays AHEAD of this step's MFMAs
+          // the three products of an element go to the same accumulator in a fixed order; consecutive MFMAs never share an accumulator
+          if constexpr (NP >= 3) {
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+              for (int f = 0; f < 2; ++f)
+                acc[ab][tile][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[buf][tile], xh[f][s], s == 0 ? zero4 : acc[ab][tile][f], 0, 0, 0);
+          }
+          if constexpr (NP >= 2) {
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+              for (int f = 0; f < 2; ++f)
+                acc[ab][tile][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[buf][tile], xl[f][s], (NP == 2 && s == 0) ? zero4 : acc[ab][tile][f], 0, 0, 0);
+          }
+#pragma unroll
+          for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+              acc[ab][tile][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[buf][tile], xh[f][s], (NP == 1 && s == 0) ? zero4 : acc[ab][tile][f], 0, 0, 0);
+          if (s == 3) {                          // - |c|^2 / 2 . 2^(shifts), after every product of the group
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) {
+              const f16x4_t pk = *reinterpret_cast<const f16x4_t*>(lds_k + 4 * (32 * gr + 16 * tile + j));
+              f16x8_t ca;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) ca[q] = (_Float16)0.f;
+              if constexpr (LUT) {
+                if (g == 0) { ca[0] = pk[0]; ca[1] = pk[0]; ca[2] = pk[1]; ca[3] = pk[1]; ca[4] = pk[2]; ca[5] = pk[2]; }
+              } else {
+                if (g == 0) { ca[0] = pk[0]; ca[1] = pk[1]; ca[2] = pk[2]; }
+              }
+#pragma unroll
+              for (int f = 0; f < 2; ++f)
+                acc[ab][tile][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca, cnb[f], acc[ab][tile][f], 0, 0, 0);
+            }
+          }
+          if (gr > 0) select4(ab ^ 1, gr - 1, s);   // the previous group's selection, one (tile, fragment) part under each step's MFMAs
+          __builtin_amdgcn_sched_barrier(0);         // keep the steps apart: hoisting every fetch to the top spills
+        }
+      }
+    }
+#pragma unroll
+    for (int part = 0; part < 4; ++part) select4(1, 7, part);
+    __builtin_amdgcn_s_barrier();
+
+    // ---- per descriptor: back to v = |c|^2 - 2 x.c (smallest = nearest), the four q-lanes combined, settled or listed
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const float m2s = -2.f * ldexpf(1.f, -(x_shift[f] + a.c_shift));   // exact: a power of two (uint8 rows: x_shift = 0, v in units of 1 / sqrt(d))
+      float b = best[f] * m2s, sc = second[f] * m2s;
+      int bi = bidx[f] + 4 * g;
+#pragma unroll
+      for (int m = 16; m <= 32; m <<= 1) {
+        const float ob = __shfl_xor(b, m, 64), os = __shfl_xor(sc, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        const bool take = ob < b || (ob == b && oi < bi);
+        const float nb = take ? ob : b, loser = take ? b : ob;
+        sc = fminf(fminf(sc, os), loser);
+        b = nb;
+        if (take) bi = oi;
+      }
+      const float xc = nx[f] * a.cmax;
+      constexpr float conv_err = DescTraits<KIND>::rootsift ? 4.8e-7f : 0.f;
+      const float cc = LUT ? a.cmax * a.cmax * lut_sd[f] : a.cmax * a.cmax;
+      constexpr float drop_err = (3 - NP) * 4.9e-4f;
+      const float eps = 2.f * (4.8e-7f + 2.4e-7f + 4.8e-5f + 7.7e-6f + 1e-9f + conv_err + drop_err) * xc * (1.f + sqrt_d * 1e-9f) + (LUT ? 6.0e-7f : 2.4e-7f) * (cc + 2.f * xc);
+      const bool settled = !(sc <= b + 2.f * eps) && finite[f] && fabsf(b) <= 3.0e38f && bi < a.K;
+      const int64_t row = blk * ASSIGN_ROWS + wave * 32 + 16 * f + j;
+      const bool amb = g == 0 && rvalid[f] && !settled;
+      const unsigned long long amask = __ballot(amb);
+      unsigned int base = 0;
+      if (amask != 0ull) {
+        if (lane == 0) base = atomicAdd(&s_count, (unsigned int)__popcll(amask));
+        base = __shfl(base, 0, 64);
+      }
+      if (g == 0 && rvalid[f]) {
+        if (settled) a.labels[row] = bi;
+        else my_rows[base + __popcll(amask & ((1ull << lane) - 1ull))] = row;
+      }
+    }
+  }
+  if (!pp_g1) __builtin_amdgcn_s_barrier();
+  __syncthreads();
+  if (threadIdx.x == 0) a.amb_count[blockIdx.x] = s_count;
+}
+
 template <int NT, int KIND>
 static int launch_assign_nt(pvs_ctx* ctx, const AssignArgs& a, bool vec, size_t lds, int grid) {
   auto kv = assign_kernel<NT, KIND, true>;
@@ -664,6 +994,9 @@ static int launch_assign16_nt(pvs_ctx* ctx, const Assign16Args& p, bool vec, siz
   auto ks = assign16_kernel<NT, KIND, false, 0>;
   auto k8 = assign16_kernel<NT, KIND, true, 8>;
   auto k = vec ? (p.D == 128 && p.D_pad16 == 128 ? k8 : kv) : ks;
+  if constexpr (NT == 8) {   // measurement variant of the shape the benchmarks use: the 16 x 16 x 32 kernel (same lists, 8-10 % slower)
+    if (k == k8 && p.nprod == 3 && p.shape16 && p.stamps == nullptr) k = assign16x_kernel<KIND, 3>;
+  }
   if constexpr (NT == 8) {   // measurement variants of the shape the benchmarks use: two products / one product per (row, cluster)
     if (k == k8 && p.nprod == 2) k = assign16_kernel<NT, KIND, true, 8, false, 2>;
     if (k == k8 && p.nprod == 1) k = assign16_kernel<NT, KIND, true, 8, false, 1>;
@@ -735,7 +1068,8 @@ int launch_assign(pvs_ctx* ctx, const pvs_codebook* cb, const void* d_desc, int 
     if (stat) *rowstat_out = rowstat;
     Assign16Args p{d_desc, total, cb->D, ld, static_cast<const _Float16*>(cb->d_c16), cb->d_cnorm, cb->K_pad, cb->D_pad16,
                    cb->c16_shift, cb->cmax, static_cast<const _Float16*>(cb->d_cnk), cb->cn_e1, cb->K, d_labels, rows, cnt, cap, rowstat,
-                   ctx->d_fused_stamps, ctx->opt[PVS_OPT_ASSIGN_PREFILTER] == 2 ? 2 : (ctx->opt[PVS_OPT_ASSIGN_PREFILTER] == 3 ? 1 : 3)};
+                   ctx->d_fused_stamps, ctx->opt[PVS_OPT_ASSIGN_PREFILTER] == 2 ? 2 : (ctx->opt[PVS_OPT_ASSIGN_PREFILTER] == 3 ? 1 : 3),
+                   ctx->opt[PVS_OPT_ASSIGN_PREFILTER] == 4 ? 1 : 0};   // .shape16
     const size_t lds16 = (size_t)2 * cb->K_pad * (128 + 8) * 2 + (size_t)cb->K_pad * 4 + (size_t)cb->K_pad * 8 + 1024;   // + the sqrt table of uint8 rows
     PVS_TRY(launch_assign16(ctx, p, kind, cb->K_pad / 32, vec, lds16, grid));
     a.rows = rows;

@@ -809,8 +809,9 @@ def test_prefiltered_assignment_equals_the_exact_kernel(gpu_ctx, tables, kind, m
     v_pre, pre = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
     assert np.array_equal(exact, pre), np.argwhere(exact != pre)[:10]
     assert not np.any(pre == 200)                    # never the later duplicate
-    # the measurement variants with two / one fp16 product(s) per (row, cluster) and the wider margin: the same labels and bits
-    for variant in (2, 3):
+    # the measurement variants with two / one fp16 product(s) per (row, cluster) and the wider margin, and (4) the three products on
+    # v_mfma_f32_16x16x32_f16 (assign16x_kernel): the same labels and bits
+    for variant in (2, 3, 4):
         with gpu_ctx.option(_ffi.OPT_ASSIGN_PREFILTER, variant):
             v_n, lab_n = gpu_ctx.vlad_encode(cb, x, off, kind, return_labels=True)
         assert np.array_equal(exact, lab_n), (variant, np.argwhere(exact != lab_n)[:10])
