@@ -254,7 +254,33 @@ def case_learn():
     rows.free()
 
 
-cases = [case_vlad, case_fisher, case_cosine_topk, case_cosine_f64, case_filtered, case_learn]
+def case_single_query():
+    """One or two queries (the dense one-pass kernel where the shape qualifies) and a resident index (pvsim.index.DeviceIndex) against
+    the same queries ranked as rows of a larger call (the MFMA tiles) / against the plain matrix: indices and scores bit for bit."""
+    from pvsim.index import DeviceIndex
+    N = int(rng.choice([1, 7, 130, 2000, 9000, 40000]))
+    L = int(rng.choice([8, 24, 30, 40, 100, 128, 1000, 1032, 4096, 32768]))      # 30 and 100: shapes the dense kernel declines
+    if N * L > 60_000_000:
+        L = 128
+    db = rng.standard_normal((N, L)).astype(np.float32)
+    if N > 3:
+        db[N // 2] = db[1]
+    q = (db[rng.integers(0, N, 140)] + 0.05 * rng.standard_normal((140, L))).astype(np.float32)
+    k = int(rng.integers(1, min(N, 50) + 1))
+    ri, rv = ctx.cosine_topk(q, db, k)                       # 140 queries: the GEMM (or filtered) path
+    for nq in (1, 2):
+        gi, gv = ctx.cosine_topk(q[:nq], db, k)
+        assert np.array_equal(gi, ri[:nq]) and np.array_equal(gv.view(np.uint32), rv[:nq].view(np.uint32)), ("single query", N, L, k, nq)
+    index = DeviceIndex({f"p{i}": db[i] for i in range(N)}, ctx)
+    try:
+        nq = int(rng.choice([1, 2, 5, 140]))
+        gi, gv = index.rank(q[:nq], k)
+        assert np.array_equal(gi, ri[:nq]) and np.array_equal(gv.view(np.uint32), rv[:nq].view(np.uint32)), ("resident index", N, L, k, nq)
+    finally:
+        index.close()
+
+
+cases = [case_vlad, case_fisher, case_cosine_topk, case_cosine_f64, case_filtered, case_learn, case_single_query]
 if os.environ.get("FUZZ_ONLY"):
     cases = [c for c in cases if c.__name__ == os.environ["FUZZ_ONLY"]]
 i = 0
