@@ -89,12 +89,13 @@ def test_corpus1m_single_gpu_filtered_equals_exact():
     assert line["self_check"]["lists_bit_identical_to_plain_exact_ranking"] is True and line["n_gpus"] == 1
 
 
-@pytest.mark.parametrize("retrieval,qflag,nq", [("f16", "--total-queries", 4096), ("filtered", "--queries", 2048)])
+@pytest.mark.parametrize("retrieval,qflag,nq", [("f16", "--total-queries", 4096), ("filtered", "--queries", 2048), ("filtered", "--queries", 2)])
 def test_corpus1m_at_its_stated_size_on_one_gpu(retrieval, qflag, nq):
     """BASELINE configs[3] / configs[4] at their stated size, on the one GPU a test has: 1,000,000 images x 512 uint8 descriptors
     generated and encoded chunk by chunk (202 GB resident), then a query block ranked against all 10^6 rows.  f16 = configs[4]'s
     fp16 MFMA similarity (recall@10 of 256 sampled queries against their exact fp32 lists); filtered = the exact lists through
-    the fp16 prefilter + fp32 re-scoring, bit-identical on 256 sampled queries to the all-pairs fp32 GEMM.  Size-independent
+    the fp16 prefilter + fp32 re-scoring, bit-identical on 256 sampled queries to the all-pairs fp32 GEMM -- and, with two queries, to the
+    dense one-pass row kernel over all 10^6 rows (what a single query against a resident index takes).  Size-independent
     properties at full size: every query retrieves itself first with score 1 (asserted inside bench.py for both paths)."""
     from conftest import REPO
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--workload", "corpus1m", "--retrieval", retrieval,
